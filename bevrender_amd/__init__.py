@@ -1,0 +1,29 @@
+"""bevrender_amd: MI355X-native (gfx950) BEV-lift + correlation hot path behind the reference's module API.
+
+Sub-packages mirror the reference's import paths (`model.*`, `loss.*`); see INTEGRATION.md for how a
+reference checkout imports them.  The arithmetic lives in csrc/ (HIP) behind include/bevrender_hip.h.
+"""
+import os
+
+from . import _lib  # noqa: F401
+
+__all__ = ["default_precision", "_lib"]
+
+
+def default_precision() -> int:
+    """BEVRENDER_PRECISION=f32|bf16 (default f32: exact-f32 MFMA; bf16 is the throughput mode)."""
+    v = os.environ.get("BEVRENDER_PRECISION", "f32").lower()
+    if v in ("bf16", "bfloat16"):
+        return _lib.PREC_BF16
+    if v in ("f32", "fp32", "float32"):
+        return _lib.PREC_F32
+    raise ValueError(f"BEVRENDER_PRECISION={v!r}: expected f32 or bf16")
+
+
+def resolve_precision(p) -> int:
+    if p is None:
+        return default_precision()
+    if isinstance(p, str):
+        return {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32,
+                "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16}[p.lower()]
+    return int(p)

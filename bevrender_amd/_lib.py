@@ -1,0 +1,95 @@
+"""ctypes binding of libbevrender_hip.so (C ABI declared in include/bevrender_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a tensor is not on a
+ROCm device the ops raise.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbevrender_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+PREC_F32, PREC_BF16 = 0, 1
+
+# every symbol include/bevrender_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "bevr_abi_version", "bevr_strerror", "bevr_attn_table_dims", "bevr_attn_fwd", "bevr_attn_bwd_q",
+    "bevr_attn_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_project_bev_grid", "bevr_corr_fwd",
+    "bevr_corr_bwd", "bevr_recall_rank",
+]
+
+
+class AttnDesc(C.Structure):
+    """struct bevr_attn_desc (include/bevrender_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_prob", "q_div", "heads", "groups", "S", "Sp", "N", "Np", "Ht", "Wt", "Hp", "Wp",
+        "y_off", "x_off", "precision", "reserved")]
+
+
+class BevrError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into bevrender_amd/lib/libbevrender_hip.so."""
+    cmd = ["make", "-C", CSRC, "-j", "4"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise BevrError("building libbevrender_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (once).  Raises BevrError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise BevrError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C bevrender_amd/csrc`.")
+        L = C.CDLL(LIB_PATH)
+        vp, fp, ip = C.c_void_p, C.c_void_p, C.c_int
+        dp = C.POINTER(AttnDesc)
+        L.bevr_abi_version.restype = C.c_int
+        L.bevr_strerror.restype = C.c_char_p
+        L.bevr_strerror.argtypes = [C.c_int]
+        L.bevr_attn_table_dims.argtypes = [dp]
+        L.bevr_attn_fwd.argtypes = [dp, vp, vp, vp, fp, fp, fp, fp, fp, vp]
+        L.bevr_attn_bwd_q.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, fp, fp, fp, fp, vp]
+        L.bevr_attn_bwd_k.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, vp, fp, fp] + [fp] * 4 + [vp]
+        L.bevr_sample_fwd.argtypes = [fp, fp, fp] + [ip] * 5 + [vp]
+        L.bevr_sample_bwd.argtypes = [fp] * 5 + [ip] * 5 + [vp]
+        L.bevr_project_bev_grid.argtypes = [fp] * 4 + [ip] * 4 + [vp]
+        L.bevr_corr_fwd.argtypes = [fp] * 5 + [ip] * 4 + [vp]
+        L.bevr_corr_bwd.argtypes = [fp] * 8 + [ip] * 4 + [vp]
+        L.bevr_recall_rank.argtypes = [fp, vp, ip, vp]
+        for name in SYMBOLS:
+            fn = getattr(L, name)
+            if name not in ("bevr_strerror",):
+                fn.restype = C.c_int
+        if L.bevr_abi_version() != 1:
+            raise BevrError("libbevrender_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = lib().bevr_strerror(code).decode()
+        raise BevrError(f"{what} failed: {msg} (code {code})")

@@ -1,0 +1,156 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 32x32 tiles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bevrender_hip.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define BEVR_LOG2E 1.4426950408889634f
+#define BEVR_LN2 0.6931471805599453f
+#define BEVR_NEG_BIG (-1.0e30f)
+
+// Row of the 32x32 MFMA accumulator held in register r by lane-half hi (cdna guide section 3):
+//   row = (r & 3) + 8 * (r >> 2) + 4 * hi ; column = lane & 31.
+__device__ __forceinline__ constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// In-32 permutation used for every operand that is contracted against an accumulator tile's rows:
+// index with bits 2 and 3 swapped (an involution).
+__host__ __device__ __forceinline__ constexpr int perm32(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// round-to-nearest-even f32 -> bf16 pair packed in one dword (plain casts lower to v_cvt_pk_bf16_f32).
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+template <int PREC> struct Elem;
+template <> struct Elem<BEVR_PREC_F32> { typedef float type; static constexpr int bytes = 4; };
+template <> struct Elem<BEVR_PREC_BF16> { typedef __bf16 type; static constexpr int bytes = 2; };
+
+// A or B operand fragment of one 32-wide tile with the 32-deep contraction held by this lane:
+//   bf16: 2 k-steps x 8 elements  (element j of step s <-> contraction index 16 s + 8 hi + j)
+//   f32 : 16 k-steps x 1 element  (step s <-> contraction index 16 hi + s)
+// In both cases the lane reads 16 *consecutive-in-memory* elements pairs: bf16 -> two 16-B chunks at
+// element offsets 8 hi and 16 + 8 hi; f32 -> 16 floats at element offset 16 hi.
+template <int PREC> struct Frag;
+template <> struct Frag<BEVR_PREC_BF16> {
+  bf16x8 v[2];
+  // row: pointer to the 32 contraction-contiguous elements of this lane's row
+  __device__ __forceinline__ void load(const void* row, int hi) {
+    const u32x4* p = reinterpret_cast<const u32x4*>(row);
+    u32x4 a = p[hi], b = p[2 + hi];
+    v[0] = __builtin_bit_cast(bf16x8, a);
+    v[1] = __builtin_bit_cast(bf16x8, b);
+  }
+};
+template <> struct Frag<BEVR_PREC_F32> {
+  float v[16];
+  __device__ __forceinline__ void load(const void* row, int hi) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(row) + 4 * hi;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 t = p[k];
+      v[4 * k + 0] = t[0]; v[4 * k + 1] = t[1]; v[4 * k + 2] = t[2]; v[4 * k + 3] = t[3];
+    }
+  }
+};
+
+// acc += A(rows x 32) * B(32 x cols) for one 32x32 tile, both operands as Frag (contraction over the
+// fragment's 32 elements in matching order).
+__device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_BF16>& a, const Frag<BEVR_PREC_BF16>& b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[0], b.v[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[1], b.v[1], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_F32>& a, const Frag<BEVR_PREC_F32>& b, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b.v[s], acc, 0, 0, 0);
+  return acc;
+}
+
+// acc += A * X where X is an ACCUMULATOR-layout tile (rows = contraction index, cols = lanes) used as
+// the B operand.  The A fragment must have been loaded from memory whose in-32 order is perm32 (see
+// bevrender_hip.h, Vt): then element j of step s of the bf16 fragment is contraction row
+// 16 s + 8 (j >> 2) + 4 hi + (j & 3) = crow(8 s + j, hi), and f32 step t is crow(t, hi).
+__device__ __forceinline__ f32x16 mma_acc_b(const Frag<BEVR_PREC_BF16>& a, const f32x16& x, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    u32x4 w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(x[8 * s + 2 * k], x[8 * s + 2 * k + 1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[s], __builtin_bit_cast(bf16x8, w), acc, 0, 0, 0);
+  }
+  return acc;
+}
+__device__ __forceinline__ f32x16 mma_acc_b(const Frag<BEVR_PREC_F32>& a, const f32x16& x, f32x16 acc) {
+  // memory order perm32: fragment element t (within this lane-half's 16) sits at position
+  // 16 (t >> 3) + 8 hi + (t & 7) of the 32-block; Frag::load read positions 16 hi .. 16 hi + 15, which is
+  // NOT that set -- the f32 A operand for an accumulator contraction is loaded with load_perm below.
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], x[t], acc, 0, 0, 0);
+  return acc;
+}
+
+// Load an A fragment for mma_acc_b from a 32-block stored in perm32 order.
+__device__ __forceinline__ void load_perm(Frag<BEVR_PREC_BF16>& f, const void* row, int hi) { f.load(row, hi); }
+__device__ __forceinline__ void load_perm(Frag<BEVR_PREC_F32>& f, const void* row, int hi) {
+  // wanted: contraction row crow(t, hi) = 8 (t>>2) + 4 hi + (t&3); its perm32 position is
+  // 16 (t>>3) + 8 hi + (t & 7).
+  const f32x4* p = reinterpret_cast<const f32x4*>(row);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 t0 = p[4 * half + 2 * hi], t1 = p[4 * half + 2 * hi + 1];
+    f.v[8 * half + 0] = t0[0]; f.v[8 * half + 1] = t0[1]; f.v[8 * half + 2] = t0[2]; f.v[8 * half + 3] = t0[3];
+    f.v[8 * half + 4] = t1[0]; f.v[8 * half + 5] = t1[1]; f.v[8 * half + 6] = t1[2]; f.v[8 * half + 7] = t1[3];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bias-tap addressing shared by the attention kernels (global-memory gather path).
+// key constants, packed per key by the kernels' prologue: Aoff (byte offset of row floor(a)+y_off
+// in column x_off), fy, clamped b, 1 - fy.
+struct KeyC { int aoff; float fy; float b; float wy0; };
+
+__device__ __forceinline__ KeyC make_keyc(float a, float b, const bevr_attn_desc& d) {
+  float aL = -(float)(d.Sp + 1), aU = (float)(d.Ht + 1);
+  float half = (float)((d.Wt) / 2);  // ceil((Wt-1)/2)
+  float bL = -(half + 2.0f), bU = (float)(d.Wt + 1);
+  // NaN-safe clamps (fminf/fmaxf return the non-NaN operand)
+  a = fminf(fmaxf(a, aL), aU);
+  b = fminf(fmaxf(b, bL), bU);
+  float af = floorf(a);
+  KeyC k;
+  k.aoff = (((int)af + d.y_off) + d.x_off * d.Hp) * 8;
+  k.fy = a - af;
+  k.wy0 = 1.0f - k.fy;
+  k.b = b;
+  return k;
+}
+
+static inline int bevr_check_desc(const bevr_attn_desc* d) {
+  if (!d) return BEVR_E_NULL;
+  if (d->n_prob <= 0 || d->q_div <= 0 || d->n_prob % d->q_div) return BEVR_E_SHAPE;
+  if (d->heads <= 0 || d->groups <= 0 || d->heads % d->groups) return BEVR_E_SHAPE;
+  if (d->S < 2 || d->Sp != 32 * ((d->S + 31) / 32)) return BEVR_E_SHAPE;
+  if (d->N <= 0 || d->Np < d->N || d->Np % 64) return BEVR_E_SHAPE;
+  if (d->Ht != 2 * d->S - 1 || d->Wt < 1) return BEVR_E_SHAPE;
+  bevr_attn_desc t = *d;
+  if (bevr_attn_table_dims(&t) != 0) return BEVR_E_SHAPE;
+  if (t.Hp != d->Hp || t.Wp != d->Wp || t.y_off != d->y_off || t.x_off != d->x_off) return BEVR_E_SHAPE;
+  if (d->precision != BEVR_PREC_F32 && d->precision != BEVR_PREC_BF16) return BEVR_E_PRECISION;
+  // 32-bit byte offsets into one head's pair table
+  if ((long long)d->Hp * d->Wp * 8 >= (1LL << 31)) return BEVR_E_SHAPE;
+  return BEVR_OK;
+}
+
+static inline int bevr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -1,0 +1,168 @@
+// Bilinear key/value feature sampling (grid_sample, align_corners=True, zero padding) on a
+// channels-last feature map, forward and backward.
+// Replaces F.grid_sample at model/SCA_deform_attn.py:290-301 and model/TSA_deform_attn.py:210-217.
+//
+// HBM-bound gather: one thread owns 4 consecutive channels of one key, so the C/4 threads of a key
+// read each of the 4 taps as one contiguous C*4-byte run (256 B at C = 64) and write one contiguous
+// output row.  Backward scatters the same runs with float atomics (contiguous 256-B shapes, the form
+// that runs at the full atomic rate) and reduces the position gradient over channels with wave
+// shuffles.
+#include "bevr_common.h"
+
+namespace {
+
+struct Taps {
+  int x0, y0;
+  float fx, fy;
+  bool vx0, vx1, vy0, vy1;
+};
+
+__device__ __forceinline__ Taps make_taps(float py, float px, int Hi, int Wi) {
+  Taps t;
+  float ix = (px + 1.0f) * 0.5f * (float)(Wi - 1);
+  float iy = (py + 1.0f) * 0.5f * (float)(Hi - 1);
+  float x0f = floorf(ix), y0f = floorf(iy);
+  t.fx = ix - x0f;
+  t.fy = iy - y0f;
+  // clamp before the int conversion so NaN / huge positions cannot index out of range
+  x0f = fminf(fmaxf(x0f, -2.0f), (float)Wi);
+  y0f = fminf(fmaxf(y0f, -2.0f), (float)Hi);
+  t.x0 = (int)x0f;
+  t.y0 = (int)y0f;
+  t.vx0 = t.x0 >= 0 && t.x0 < Wi;
+  t.vx1 = t.x0 + 1 >= 0 && t.x0 + 1 < Wi;
+  t.vy0 = t.y0 >= 0 && t.y0 < Hi;
+  t.vy1 = t.y0 + 1 >= 0 && t.y0 + 1 < Hi;
+  return t;
+}
+
+__global__ __launch_bounds__(256) void sample_fwd_kernel(const float* __restrict__ feat,
+                                                         const float* __restrict__ pos, float* __restrict__ out,
+                                                         int nb, int Hi, int Wi, int C, int N) {
+  const int c4n = C >> 2;
+  const long long total = (long long)nb * N * c4n;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % c4n);
+    const long long kn = idx / c4n;  // b * N + n
+    const int b = (int)(kn / N);
+    const f32x2 p = *reinterpret_cast<const f32x2*>(pos + kn * 2);
+    const Taps t = make_taps(p[0], p[1], Hi, Wi);
+    const float* fb = feat + (size_t)b * Hi * Wi * C + c4 * 4;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v00 = (t.vy0 && t.vx0) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)t.y0 * Wi + t.x0) * C) : z;
+    f32x4 v01 = (t.vy0 && t.vx1) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)t.y0 * Wi + t.x0 + 1) * C) : z;
+    f32x4 v10 = (t.vy1 && t.vx0) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)(t.y0 + 1) * Wi + t.x0) * C) : z;
+    f32x4 v11 = (t.vy1 && t.vx1) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)(t.y0 + 1) * Wi + t.x0 + 1) * C) : z;
+    const float w00 = (1.f - t.fx) * (1.f - t.fy), w01 = t.fx * (1.f - t.fy);
+    const float w10 = (1.f - t.fx) * t.fy, w11 = t.fx * t.fy;
+    f32x4 r = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+    *reinterpret_cast<f32x4*>(out + kn * C + c4 * 4) = r;
+  }
+}
+
+// One key per group of G = C/4 lanes (G a power of two <= 64 is reduced with shuffles; otherwise the
+// position gradient is added with atomics per thread).
+__global__ __launch_bounds__(256) void sample_bwd_kernel(const float* __restrict__ feat,
+                                                         const float* __restrict__ pos,
+                                                         const float* __restrict__ dout,
+                                                         float* __restrict__ dfeat, float* __restrict__ dpos,
+                                                         int nb, int Hi, int Wi, int C, int N, int pow2_group) {
+  const int c4n = C >> 2;
+  const long long total = (long long)nb * N * c4n;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  // total is padded up so that whole waves stay converged for the shuffles
+  const long long padded = (total + 63) / 64 * 64;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < padded; idx += stride) {
+    const bool live = idx < total;
+    const long long id = live ? idx : total - 1;
+    const int c4 = (int)(id % c4n);
+    const long long kn = id / c4n;
+    const int b = (int)(kn / N);
+    const f32x2 p = *reinterpret_cast<const f32x2*>(pos + kn * 2);
+    const Taps t = make_taps(p[0], p[1], Hi, Wi);
+    const size_t fo = (size_t)b * Hi * Wi * C + c4 * 4;
+    const float* fb = feat + fo;
+    float* gb = dfeat + fo;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 g = live ? *reinterpret_cast<const f32x4*>(dout + kn * C + c4 * 4) : z;
+    const bool b00 = t.vy0 && t.vx0, b01 = t.vy0 && t.vx1, b10 = t.vy1 && t.vx0, b11 = t.vy1 && t.vx1;
+    const size_t o00 = ((size_t)t.y0 * Wi + t.x0) * C, o01 = o00 + C, o10 = o00 + (size_t)Wi * C, o11 = o10 + C;
+    f32x4 v00 = b00 ? *reinterpret_cast<const f32x4*>(fb + o00) : z;
+    f32x4 v01 = b01 ? *reinterpret_cast<const f32x4*>(fb + o01) : z;
+    f32x4 v10 = b10 ? *reinterpret_cast<const f32x4*>(fb + o10) : z;
+    f32x4 v11 = b11 ? *reinterpret_cast<const f32x4*>(fb + o11) : z;
+    const float w00 = (1.f - t.fx) * (1.f - t.fy), w01 = t.fx * (1.f - t.fy);
+    const float w10 = (1.f - t.fx) * t.fy, w11 = t.fx * t.fy;
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (b00) atomicAdd(gb + o00 + k, g[k] * w00);
+        if (b01) atomicAdd(gb + o01 + k, g[k] * w01);
+        if (b10) atomicAdd(gb + o10 + k, g[k] * w10);
+        if (b11) atomicAdd(gb + o11 + k, g[k] * w11);
+      }
+    }
+    // d out / d ix = (v01 - v00)(1 - fy) + (v11 - v10) fy ; d out / d iy = (v10 - v00)(1 - fx) + (v11 - v01) fx
+    float gx = 0.f, gy = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gx += g[k] * ((v01[k] - v00[k]) * (1.f - t.fy) + (v11[k] - v10[k]) * t.fy);
+      gy += g[k] * ((v10[k] - v00[k]) * (1.f - t.fx) + (v11[k] - v01[k]) * t.fx);
+    }
+    gx *= 0.5f * (float)(Wi - 1);
+    gy *= 0.5f * (float)(Hi - 1);
+    if (pow2_group) {
+      for (int sh = c4n >> 1; sh > 0; sh >>= 1) {
+        gx += __shfl_xor(gx, sh);
+        gy += __shfl_xor(gy, sh);
+      }
+      if (live && c4 == 0) {
+        f32x2 o = {gy, gx};
+        *reinterpret_cast<f32x2*>(dpos + kn * 2) = o;
+      }
+    } else if (live) {
+      atomicAdd(dpos + kn * 2, gy);
+      atomicAdd(dpos + kn * 2 + 1, gx);
+    }
+  }
+}
+
+int grid_for(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;  // grid-stride the rest
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int bevr_sample_fwd(const float* feat, const float* pos, float* out, int nb, int Hi, int Wi, int C,
+                               int N, void* stream) {
+  if (!feat || !pos || !out) return BEVR_E_NULL;
+  if (nb <= 0 || Hi < 2 || Wi < 2 || N <= 0 || C <= 0 || (C & 3) || C > 1024) return BEVR_E_SHAPE;
+  if (!bevr_aligned16(feat) || !bevr_aligned16(out) || (reinterpret_cast<uintptr_t>(pos) & 7)) return BEVR_E_ALIGN;
+  long long total = (long long)nb * N * (C >> 2);
+  hipLaunchKernelGGL(sample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, feat, pos, out,
+                     nb, Hi, Wi, C, N);
+  return (int)hipGetLastError();
+}
+
+extern "C" int bevr_sample_bwd(const float* feat, const float* pos, const float* dout, float* dfeat, float* dpos,
+                               int nb, int Hi, int Wi, int C, int N, void* stream) {
+  if (!feat || !pos || !dout || !dfeat || !dpos) return BEVR_E_NULL;
+  if (nb <= 0 || Hi < 2 || Wi < 2 || N <= 0 || C <= 0 || (C & 3) || C > 1024) return BEVR_E_SHAPE;
+  if (!bevr_aligned16(feat) || !bevr_aligned16(dout) || !bevr_aligned16(dfeat) ||
+      (reinterpret_cast<uintptr_t>(pos) & 7) || (reinterpret_cast<uintptr_t>(dpos) & 7))
+    return BEVR_E_ALIGN;
+  const int c4n = C >> 2;
+  const int pow2 = (c4n <= 64 && (c4n & (c4n - 1)) == 0) ? 1 : 0;
+  if (!pow2) {
+    hipError_t e = hipMemsetAsync(dpos, 0, (size_t)nb * N * 2 * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  long long total = (long long)nb * N * c4n;
+  hipLaunchKernelGGL(sample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, feat, pos, dout,
+                     dfeat, dpos, nb, Hi, Wi, C, N, pow2);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,99 @@
+"""Spatial cross-attention (the camera -> BEV "lift") on the gfx950 kernels.
+
+Counterpart of the reference's model/SCA_deform_attn.py (:14-165 constructor, :180-421 forward): same
+class name, constructor arguments, forward signature and parameter names.  Differences, all forced by
+the reference itself:
+  * every view v < n_views gets an offset head `conv_offset_m{v}` of the m0 form (D output channels);
+    the reference's m1/m2 heads emit 2*D channels and raise in its own rearrange, so n_views > 1 has no
+    reference semantics.  Heads m1/m2 that a n_views < 3 model does not use are still created with the
+    reference's shapes so its state_dict loads unchanged.
+  * the batch size is read from the tensors (data-parallel shards), not from the constructor.
+All views are batched into one sampling launch and one attention launch.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops, resolve_precision
+from .model_utils import LayerNormProxy, trunc_normal_
+
+
+class SCADeformableAttention(nn.Module):
+    def __init__(self, bev_feat_shape, bev_depth_dim, dim_embed, n_heads, n_groups, stride, kernel_size,
+                 scale_offset_range, batch_size, n_views=3, attn_drop_rate=0.0, proj_drop_rate=0.0,
+                 data_type=torch.float32, logger=None, precision=None):
+        super().__init__()
+        self.n_channel_per_head = dim_embed // n_heads
+        self.scale = self.n_channel_per_head ** -0.5
+        self.n_heads = n_heads
+        self.embed_dim = self.n_channel_per_head * n_heads
+        self.n_groups = n_groups
+        self.n_channel_per_group = self.embed_dim // n_groups
+        self.n_heads_per_group = n_heads // n_groups
+        self.query_height = self.query_width = bev_feat_shape
+        self.bev_depth_dim = bev_depth_dim
+        self.batch_size = batch_size
+        self.scale_offset_range = scale_offset_range
+        self.kernel_size, self.stride, self.n_views = kernel_size, stride, n_views
+        self.data_type, self.logger = data_type, logger
+        self.offset_range_factor = 5.0
+        self.precision = resolve_precision(precision)
+        if attn_drop_rate or proj_drop_rate:
+            raise NotImplementedError("dropout inside the fused attention is not supported (reference default 0)")
+        cg, D = self.n_channel_per_group, bev_depth_dim
+
+        def head(out_ch):
+            return nn.Sequential(nn.Conv2d(cg, cg * D, 1, 1, 0, groups=cg), LayerNormProxy(cg * D), nn.GELU(),
+                                 nn.Conv2d(cg * D, out_ch, 1, 1, 0, bias=False))
+
+        for v in range(max(n_views, 3)):
+            used = v < n_views
+            setattr(self, f"conv_offset_m{v}", head(D if (used or v == 0) else 2 * D))
+        C = self.embed_dim
+        self.proj_q = nn.Conv2d(C, C, 1)      # unused by the reference forward (:304-306)
+        self.proj_k = nn.Conv2d(C, C, 1)
+        self.proj_v = nn.Conv2d(C, C, 1)
+        self.proj_out = nn.Conv2d(C * n_views, C, 1)
+        self.proj_views = nn.Conv2d(cg * n_views, cg, 1)   # unused, state_dict parity
+        self.rpe_table = nn.Parameter(torch.zeros(n_heads, 2 * bev_feat_shape - 1, 2 * bev_feat_shape * D - 1))
+        trunc_normal_(self.rpe_table, std=0.01)
+
+    def key_positions(self, query, reference_points):
+        """(B, V, g, N, 2) key positions (y, x): offset head of each view, even BEV rows -> y-offset of key
+        row h, odd rows -> x-offset, key column w*D + d (reference :219-277)."""
+        B, C, S, _ = query.shape
+        g, D, V = self.n_groups, self.bev_depth_dim, self.n_views
+        Hk, Wk = S // 2, S * D
+        qg = query.reshape(B * g, C // g, S, S)
+        ref = reference_points[..., (1, 0)]                                  # (B, V, Hk, Wk, 2) -> (y, x)
+        outs = []
+        for v in range(V):
+            off = getattr(self, f"conv_offset_m{v}")(qg)                     # (B*g, D, S, S)
+            off = off.reshape(B * g, D, Hk, 2, S).permute(0, 3, 2, 4, 1).reshape(B * g, 2, Hk, Wk)
+            if self.scale_offset_range:
+                rng = off.new_tensor([1.0 / (Hk - 1.0), 1.0 / (Wk - 1.0)]).reshape(1, 2, 1, 1)
+                off = off.tanh() * rng * self.offset_range_factor
+            pos = off.permute(0, 2, 3, 1).reshape(B, g, Hk, Wk, 2) + ref[:, v, None]
+            if not self.scale_offset_range:
+                pos = pos.clamp(-1.0, 1.0)
+            outs.append(pos.reshape(B, g, Hk * Wk, 2))
+        return torch.stack(outs, 1)
+
+    def forward(self, x, query, reference_points, wandb_log_dict, return_wandb_log=True):
+        """x (B, V, C, Hi, Wi); query (B, C, S, S); reference_points (B, V, S/2, S*D, 2) in (x, y)."""
+        B, V, C, Hi, Wi = x.shape
+        S = query.shape[-1]
+        if V != self.n_views:
+            raise ValueError(f"expected {self.n_views} views, got {V}")
+        g = self.n_groups
+        pos = self.key_positions(query, reference_points.to(query.dtype))       # (B, V, g, N, 2)
+        N = pos.shape[3]
+        pos = pos.reshape(B * V * g, N, 2)
+        xs = ops.sample_features(x.reshape(B * V, C, Hi, Wi), pos, g)            # (B*V, N, C)
+        k = F.linear(xs, self.proj_k.weight.flatten(1), self.proj_k.bias)
+        v = F.linear(xs, self.proj_v.weight.flatten(1), self.proj_v.bias)
+        o = ops.attention_core(query, k, v, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
+                               precision=self.precision)                         # (B*V, S*S, C)
+        o = o.reshape(B, V, S * S, C).permute(0, 2, 1, 3).reshape(B, S * S, V * C)
+        out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
+        return out.permute(0, 2, 1).reshape(B, C, S, S), wandb_log_dict

@@ -1,0 +1,80 @@
+"""Temporal self-attention over sampled keys of the previous BEV, on the gfx950 kernels.
+
+Counterpart of the reference's model/TSA_deform_attn.py (class name, constructor arguments, parameter
+names and forward signature identical; :14-96, :128-337).  The offset head and the three 1x1
+projections stay stock PyTorch (MIOpen / rocBLAS); the bilinear sampling of prev_bev and the whole
+QK^T + RPE-bias + softmax + PV core run in libbevrender_hip.so (ops.sample_features, ops.attention_core).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops, resolve_precision
+from .model_utils import LayerNormProxy, normalized_grid, trunc_normal_
+
+
+class TSADeformableAttention(nn.Module):
+    def __init__(self, bev_feat_shape, dim_embed, n_heads, n_groups, stride, kernel_size, scale_offset_range,
+                 batch_size, n_views=3, attn_drop_rate=0.0, proj_drop_rate=0.0, data_type=torch.float32,
+                 logger=None, precision=None):
+        super().__init__()
+        self.n_channel_per_head = dim_embed // n_heads
+        self.scale = self.n_channel_per_head ** -0.5
+        self.n_heads = n_heads
+        self.embed_dim = self.n_channel_per_head * n_heads
+        self.n_groups = n_groups
+        self.n_channel_per_group = self.embed_dim // n_groups
+        self.n_heads_per_group = n_heads // n_groups
+        self.bev_h = self.bev_w = bev_feat_shape
+        self.batch_size = batch_size          # kept for API parity; the batch is read from the tensors
+        self.scale_offset_range = scale_offset_range
+        self.kernel_size, self.stride, self.n_views = kernel_size, stride, n_views
+        self.data_type, self.logger = data_type, logger
+        self.offset_range_factor = 0.5
+        self.precision = resolve_precision(precision)
+        if attn_drop_rate or proj_drop_rate:
+            raise NotImplementedError("dropout inside the fused attention is not supported (reference default 0)")
+        pad = kernel_size // 2 if kernel_size != stride else 0
+        cg = self.n_channel_per_group
+        self.conv_offset = nn.Sequential(
+            nn.Conv2d(cg, cg, kernel_size, stride, pad, groups=cg),
+            LayerNormProxy(cg),
+            nn.GELU(),
+            nn.Conv2d(cg, 2, 1, 1, 0, bias=False),
+        )
+        C = self.embed_dim
+        self.proj_q = nn.Conv2d(C, C, 1)       # constructed, never used by the reference forward (:220)
+        self.proj_k = nn.Conv2d(C, C, 1)
+        self.proj_v = nn.Conv2d(C, C, 1)
+        self.proj_out = nn.Conv2d(C, C, 1)
+        self.proj_views = nn.Conv2d(cg * n_views, cg, 1)   # unused, kept for state_dict parity
+        self.rpe_table = nn.Parameter(torch.zeros(n_heads, 2 * self.bev_h - 1, 2 * self.bev_w - 1))
+        trunc_normal_(self.rpe_table, std=0.01)
+
+    def key_positions(self, query):
+        """offset head -> tanh range -> + regular grid: (B*g, Hk*Wk, 2) in (y, x).  reference :158-196."""
+        B, C, H, W = query.shape
+        g = self.n_groups
+        off = self.conv_offset(query.reshape(B * g, C // g, H, W))
+        Hk, Wk = off.shape[-2:]
+        if self.scale_offset_range:
+            rng = off.new_tensor([1.0 / (Hk - 1.0), 1.0 / (Wk - 1.0)]).reshape(1, 2, 1, 1)
+            off = off.tanh() * rng * self.offset_range_factor
+        pos = off.permute(0, 2, 3, 1) + normalized_grid(Hk, Wk, off.dtype, off.device)[None]
+        if not self.scale_offset_range:
+            pos = pos.clamp(-1.0, 1.0)
+        return pos.reshape(B * g, Hk * Wk, 2)
+
+    def forward(self, x, query, wandb_log_dict, return_wandb_log=True):
+        if x is None:                       # no history: self-attention on the query (:142-143)
+            x = query
+        B, C, H, W = x.shape
+        pos = self.key_positions(query)
+        xs = ops.sample_features(x, pos, self.n_groups)                                  # (B, N, C)
+        k = F.linear(xs, self.proj_k.weight.flatten(1), self.proj_k.bias)
+        v = F.linear(xs, self.proj_v.weight.flatten(1), self.proj_v.bias)
+        o = ops.attention_core(query, k, v, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
+                               views=1, precision=self.precision)                        # (B, H*W, C)
+        out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
+        out = out.permute(0, 2, 1).reshape(B, C, H, W)
+        return out, wandb_log_dict

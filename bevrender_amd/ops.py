@@ -1,0 +1,331 @@
+"""Host side of the HIP kernels: geometry, packed layouts and autograd wiring.
+
+Everything that is pure layout (NCHW <-> the kernels' packed orders, scaling by head_dim^-0.5 log2 e,
+table transposition/padding) is ordinary differentiable torch code, so autograd undoes it for free;
+the arithmetic of the hot path (feature sampling, QK^T + RPE bias + softmax + PV, correlation) runs in
+libbevrender_hip.so through the C ABI in include/bevrender_hip.h.  There is no CPU implementation
+here: tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+LOG2E = 1.4426950408889634
+HEAD_DIM = 32  # kernels' fixed head width (reference dims/heads is always 32); smaller heads are zero padded
+
+
+def perm32(r: int) -> int:
+    """bits 2 and 3 swapped: the order an MFMA accumulator tile is consumed in (bevr_common.h)."""
+    return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+
+
+_PERM_CACHE = {}
+
+
+def perm_index(n: int, device) -> torch.Tensor:
+    """index tensor idx with idx[p] = 32*(p//32) + perm32(p%32); n must be a multiple of 32."""
+    key = (n, str(device))
+    if key not in _PERM_CACHE:
+        base = torch.arange(n, device=device)
+        r = base % 32
+        pr = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+        _PERM_CACHE[key] = (base - r + pr)
+    return _PERM_CACHE[key]
+
+
+@dataclass(frozen=True)
+class AttnGeom:
+    """Mirror of struct bevr_attn_desc with the derived paddings."""
+    n_prob: int
+    q_div: int
+    heads: int
+    groups: int
+    S: int
+    N: int
+    Wt: int
+    precision: int
+
+    @property
+    def Sp(self): return 32 * ((self.S + 31) // 32)
+    @property
+    def Mp(self): return self.S * self.Sp
+    @property
+    def Np(self): return 64 * ((self.N + 63) // 64)
+    @property
+    def Ht(self): return 2 * self.S - 1
+    @property
+    def y_off(self): return self.Sp + 2
+    @property
+    def Hp(self): return self.Ht + 2 * self.Sp + 4
+    @property
+    def x_off(self): return self.Wt // 2 + 4
+    @property
+    def Wp(self): return self.Wt + 2 * (self.Wt // 2) + 9
+    @property
+    def rx(self): return (self.Wt - 1) / (2.0 * (self.S - 1))
+
+    def desc(self) -> _lib.AttnDesc:
+        return _lib.AttnDesc(self.n_prob, self.q_div, self.heads, self.groups, self.S, self.Sp, self.N, self.Np,
+                             self.Ht, self.Wt, self.Hp, self.Wp, self.y_off, self.x_off, self.precision, 0)
+
+
+# --------------------------------------------------------------------------------------------------
+# packed layouts (differentiable torch code; also exercised on CPU by tests/test_packing_cpu.py)
+# --------------------------------------------------------------------------------------------------
+def pack_query(query: torch.Tensor, heads: int) -> torch.Tensor:
+    """(B, C, S, S) NCHW raw (layer-normed) query -> (B, h, Mp, 32), packed index j*Sp + i, scaled by
+    c^-0.5 * log2(e).  The reference uses the raw query as Q (model/SCA_deform_attn.py:304-306)."""
+    B, Cc, S, _ = query.shape
+    c = Cc // heads
+    if c > HEAD_DIM:
+        raise ValueError(f"head_dim {c} > {HEAD_DIM} is not supported by the gfx950 kernels")
+    Sp = 32 * ((S + 31) // 32)
+    q = query.reshape(B, heads, c, S, S) * (c ** -0.5 * LOG2E)
+    q = q.permute(0, 1, 4, 3, 2)                      # (B, h, j, i, c)
+    q = F.pad(q, (0, HEAD_DIM - c, 0, Sp - S))
+    return q.reshape(B, heads, S * Sp, HEAD_DIM)
+
+
+def pack_keys(x: torch.Tensor, heads: int) -> torch.Tensor:
+    """(B', N, C) projected keys or values -> (B', h, Np, 32) row layout (zero padded)."""
+    Bp, N, Cc = x.shape
+    c = Cc // heads
+    Np = 64 * ((N + 63) // 64)
+    k = x.reshape(Bp, N, heads, c).permute(0, 2, 1, 3)
+    return F.pad(k, (0, HEAD_DIM - c, 0, Np - N))
+
+
+def unpack_out(O: torch.Tensor, S: int, c: int) -> torch.Tensor:
+    """(B', h, Mp, 32) -> (B', S*S, h*c) with the row index i*S + j (the reference's flattening)."""
+    Bp, h, Mp, _ = O.shape
+    Sp = Mp // S
+    o = O.reshape(Bp, h, S, Sp, HEAD_DIM)[:, :, :, :S, :c]          # (B', h, j, i, c)
+    return o.permute(0, 3, 2, 1, 4).reshape(Bp, S * S, h * c)
+
+
+def key_coords(pos: torch.Tensor, S: int, Wt: int, Np: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pos (P, N, 2) in (y, x), [-1, 1] units -> table coordinates a (rows), b (cols), padded to Np.
+    ty = i + a, tx = j*rx + b reproduces grid_sample(align_corners=True) of (q_grid - pos)/2
+    (model/SCA_deform_attn.py:365-389): ((q - p)/2 + 1)/2 * (size - 1)."""
+    a = (1.0 - pos[..., 0]) * ((S - 1) / 2.0)
+    b = (1.0 - pos[..., 1]) * ((Wt - 1) / 4.0)
+    N = pos.shape[1]
+    return F.pad(a, (0, Np - N)).contiguous(), F.pad(b, (0, Np - N)).contiguous()
+
+
+def pack_table(rpe_table: torch.Tensor, g: AttnGeom) -> torch.Tensor:
+    """(h, Ht, Wt) -> transposed, zero padded, times log2(e): (h, Wp, Hp + 1)."""
+    t = rpe_table * LOG2E
+    t = F.pad(t, (g.x_off, g.Wp - g.Wt - g.x_off, g.y_off, g.Hp + 1 - g.Ht - g.y_off))
+    return t.transpose(1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------
+# kernel launchers
+# --------------------------------------------------------------------------------------------------
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.BevrError("bevrender_amd ops need ROCm device tensors; there is no CPU fallback")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _edtype(precision: int):
+    return torch.bfloat16 if precision == _lib.PREC_BF16 else torch.float32
+
+
+def _perm_t(x: torch.Tensor) -> torch.Tensor:
+    """(.., L, 32) row layout -> (.., 32, L) with the in-32 permutation over L (Vt / Kt / Qt / dOt)."""
+    L = x.shape[-2]
+    return x.index_select(-2, perm_index(L, x.device)).transpose(-1, -2).contiguous()
+
+
+class _AttnCore(torch.autograd.Function):
+    """O = softmax(Q K^T + bias(a, b, table)) V in packed layouts (all inputs float32)."""
+
+    @staticmethod
+    def forward(ctx, Qp, Kp, Vp, key_a, key_b, Tt, geom: AttnGeom):
+        _require_gpu(Qp, Kp, Vp, key_a, key_b, Tt)
+        L = _lib.lib()
+        ed = _edtype(geom.precision)
+        Qe, Ke, Ve = Qp.to(ed).contiguous(), Kp.to(ed).contiguous(), Vp.to(ed).contiguous()
+        Vt = _perm_t(Ve)
+        key_a, key_b = key_a.contiguous(), key_b.contiguous()
+        Ttc = Tt.contiguous()
+        pair = torch.stack((Ttc[..., :-1], Ttc[..., 1:]), dim=-1).contiguous()   # (h, Wp, Hp, 2)
+        O = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=Qp.device, dtype=torch.float32)
+        LSE = torch.empty(geom.n_prob, geom.heads, geom.Mp, device=Qp.device, dtype=torch.float32)
+        d = geom.desc()
+        _lib.check(L.bevr_attn_fwd(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Vt), _ptr(key_a), _ptr(key_b),
+                                   _ptr(pair), _ptr(O), _ptr(LSE), _stream()), "bevr_attn_fwd")
+        ctx.geom = geom
+        ctx.save_for_backward(Qe, Ke, Ve, key_a, key_b, pair, O, LSE)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        geom: AttnGeom = ctx.geom
+        Qe, Ke, Ve, key_a, key_b, pair, O, LSE = ctx.saved_tensors
+        L = _lib.lib()
+        ed = _edtype(geom.precision)
+        dO = dO.contiguous()
+        delta = (dO * O).sum(-1).contiguous()
+        dOe = dO.to(ed).contiguous()
+        dev = dO.device
+        d = geom.desc()
+        dQ = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
+        dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
+        Kt = _perm_t(Ke)
+        _lib.check(L.bevr_attn_bwd_q(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_a), _ptr(key_b),
+                                     _ptr(pair), _ptr(dOe), _ptr(LSE), _ptr(delta), _ptr(dQ), _ptr(dT), _stream()),
+                   "bevr_attn_bwd_q")
+        del Kt
+        dK = torch.empty(geom.n_prob, geom.heads, geom.Np, HEAD_DIM, device=dev, dtype=torch.float32)
+        dV = torch.empty_like(dK)
+        da = torch.zeros_like(key_a)
+        db = torch.zeros_like(key_b)
+        Qt = _perm_t(Qe)
+        dOt = _perm_t(dOe)
+        _lib.check(L.bevr_attn_bwd_k(C.byref(d), _ptr(Qe), _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(key_a), _ptr(key_b),
+                                     _ptr(pair), _ptr(dOe), _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(dK), _ptr(dV),
+                                     _ptr(da), _ptr(db), _stream()), "bevr_attn_bwd_k")
+        if geom.q_div > 1:  # the views of one sample share the query: sum their query gradients
+            dQ = dQ.reshape(geom.n_prob // geom.q_div, geom.q_div, geom.heads, geom.Mp, HEAD_DIM).sum(1)
+        return dQ, dK, dV, da, db, dT, None
+
+
+def attention_core(query: torch.Tensor, kproj: torch.Tensor, vproj: torch.Tensor, pos: torch.Tensor,
+                   rpe_table: torch.Tensor, *, heads: int, groups: int, views: int, precision: int) -> torch.Tensor:
+    """Fused attention of the BEV query against sampled keys.
+
+    query (B, C, S, S) layer-normed BEV query (used raw as Q); kproj, vproj (B*views, N, C) projected
+    sampled features; pos (B*views*groups, N, 2) key positions (y, x); rpe_table (h, 2S-1, Wt).
+    Returns (B*views, S*S, C): per view softmax(QK^T c^-0.5 + bias) V, rows in i*S + j order.
+    Replaces model/SCA_deform_attn.py:304-413 / model/TSA_deform_attn.py:220-333.
+    """
+    B, Cc, S, _ = query.shape
+    Bp, N, _ = kproj.shape
+    c = Cc // heads
+    geom = AttnGeom(n_prob=Bp, q_div=views, heads=heads, groups=groups, S=S, N=N, Wt=rpe_table.shape[-1],
+                    precision=precision)
+    if rpe_table.shape[-2] != 2 * S - 1:
+        raise ValueError("rpe_table height must be 2S-1")
+    Qp = pack_query(query.float(), heads)
+    Kp = pack_keys(kproj.float(), heads)
+    Vp = pack_keys(vproj.float(), heads)
+    a, b = key_coords(pos.float(), S, geom.Wt, geom.Np)
+    Tt = pack_table(rpe_table.float(), geom)
+    O = _AttnCore.apply(Qp, Kp, Vp, a, b, Tt, geom)
+    return unpack_out(O, S, c)
+
+
+class _Sample(torch.autograd.Function):
+    """grid_sample(bilinear, align_corners=True, zeros) on a channels-last map: (nb,Hi,Wi,C),(nb,N,2)->(nb,N,C)."""
+
+    @staticmethod
+    def forward(ctx, feat, pos):
+        _require_gpu(feat, pos)
+        feat, pos = feat.contiguous(), pos.contiguous()
+        nb, Hi, Wi, Cc = feat.shape
+        N = pos.shape[1]
+        out = torch.empty(nb, N, Cc, device=feat.device, dtype=torch.float32)
+        _lib.check(_lib.lib().bevr_sample_fwd(_ptr(feat), _ptr(pos), _ptr(out), nb, Hi, Wi, Cc, N, _stream()),
+                   "bevr_sample_fwd")
+        ctx.save_for_backward(feat, pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, pos = ctx.saved_tensors
+        nb, Hi, Wi, Cc = feat.shape
+        N = pos.shape[1]
+        dout = dout.contiguous()
+        dfeat = torch.zeros_like(feat)
+        dpos = torch.empty_like(pos)
+        _lib.check(_lib.lib().bevr_sample_bwd(_ptr(feat), _ptr(pos), _ptr(dout), _ptr(dfeat), _ptr(dpos), nb, Hi, Wi,
+                                              Cc, N, _stream()), "bevr_sample_bwd")
+        return dfeat, dpos
+
+
+def sample_features(feat_nchw: torch.Tensor, pos: torch.Tensor, groups: int) -> torch.Tensor:
+    """feat (B, C, Hi, Wi), pos (B*g, N, 2) (y, x) -> sampled (B, N, C).  Group gi's channels are sampled at
+    group gi's positions (model/SCA_deform_attn.py:290-301: x.reshape(B*g, C/g, Hi, Wi))."""
+    B, Cc, Hi, Wi = feat_nchw.shape
+    g = groups
+    N = pos.shape[1]
+    f = feat_nchw.float().reshape(B, g, Cc // g, Hi, Wi).permute(0, 1, 3, 4, 2).reshape(B * g, Hi, Wi, Cc // g)
+    xs = _Sample.apply(f.contiguous(), pos.float())
+    return xs.reshape(B, g, N, Cc // g).permute(0, 2, 1, 3).reshape(B, N, Cc)
+
+
+def project_bev_grid(points_3d: torch.Tensor, cam_inv: torch.Tensor, Kmat: torch.Tensor, img_w: int,
+                     img_h: int) -> torch.Tensor:
+    """points_3d (4, P), cam_inv (ncam, 4, 4), Kmat (ncam, 3, 3) -> (ncam, 2, P) normalised (x, y)."""
+    _require_gpu(points_3d, cam_inv, Kmat)
+    pts = points_3d.float().contiguous()
+    ci, km = cam_inv.float().contiguous(), Kmat.float().contiguous()
+    ncam, P = ci.shape[0], pts.shape[1]
+    out = torch.empty(ncam, 2, P, device=pts.device, dtype=torch.float32)
+    _lib.check(_lib.lib().bevr_project_bev_grid(_ptr(pts), _ptr(ci), _ptr(km), _ptr(out), ncam, P, img_w, img_h,
+                                                _stream()), "bevr_project_bev_grid")
+    return out
+
+
+class _Corr(torch.autograd.Function):
+    """D = 2 - 2 cam map^T on raw or L2-normalised rows."""
+
+    @staticmethod
+    def forward(ctx, cam, mp, normalize: bool):
+        _require_gpu(cam, mp)
+        cam, mp = cam.float().contiguous(), mp.float().contiguous()
+        n, E = cam.shape
+        m = mp.shape[0]
+        D = torch.empty(n, m, device=cam.device, dtype=torch.float32)
+        inc = torch.empty(n, device=cam.device, dtype=torch.float32)
+        inm = torch.empty(m, device=cam.device, dtype=torch.float32)
+        _lib.check(_lib.lib().bevr_corr_fwd(_ptr(cam), _ptr(mp), _ptr(D), _ptr(inc), _ptr(inm), n, m, E,
+                                            int(normalize), _stream()), "bevr_corr_fwd")
+        ctx.normalize = normalize
+        ctx.save_for_backward(cam, mp, D, inc, inm)
+        return D
+
+    @staticmethod
+    def backward(ctx, dD):
+        cam, mp, D, inc, inm = ctx.saved_tensors
+        n, E = cam.shape
+        m = mp.shape[0]
+        dcam, dmap = torch.empty_like(cam), torch.empty_like(mp)
+        _lib.check(_lib.lib().bevr_corr_bwd(_ptr(cam), _ptr(mp), _ptr(D), _ptr(dD.contiguous()), _ptr(inc), _ptr(inm),
+                                            _ptr(dcam), _ptr(dmap), n, m, E, int(ctx.normalize), _stream()),
+                   "bevr_corr_bwd")
+        return dcam, dmap, None
+
+
+def pairwise_corr(cam: torch.Tensor, mp: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+    """2 - 2 cam map^T (train.py:554); normalize=True L2-normalises rows first (retrieval losses)."""
+    return _Corr.apply(cam, mp, normalize)
+
+
+def recall_rank(D: torch.Tensor) -> torch.Tensor:
+    """rank[k] = #{i : D[i, k] < D[k, k]}  (train.py:559-563)."""
+    _require_gpu(D)
+    D = D.float().contiguous()
+    n = D.shape[0]
+    rank = torch.empty(n, device=D.device, dtype=torch.int32)
+    _lib.check(_lib.lib().bevr_recall_rank(_ptr(D), _ptr(rank), n, _stream()), "bevr_recall_rank")
+    return rank

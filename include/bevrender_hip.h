@@ -1,0 +1,162 @@
+/*
+ * bevrender_hip.h -- C ABI of libbevrender_hip.so: the MI355X (gfx950) kernels behind the
+ * BEV-lift + correlation hot path of rpl-cmu/bevrender.
+ *
+ * The reference has no FFI: its boundary is Python nn.Module.forward.  The
+ * Python modules in bevrender_amd/model/ mirror that interface and bind these entry points with
+ * ctypes (bevrender_amd/_lib.py); INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA storage) unless named host_*;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all calls are asynchronous
+ *     on that stream, allocate nothing and never synchronise (graph-capture safe);
+ *   - return value: 0 on success, a negative BEVR_E_* code when the arguments violate the stated
+ *     contract (nothing is launched), a positive hipError_t if the launch itself failed;
+ *   - tensors are dense row-major with the layouts written next to each argument.
+ *
+ * Reference functions replaced (paths relative to the reference repo):
+ *   bevr_project_bev_grid   model/bev_cmr_proj.py:61-113  (bev_grid_to_camera + get_in_bound_mask)
+ *   bevr_sample_fwd/bwd     F.grid_sample at model/SCA_deform_attn.py:290-301, model/TSA_deform_attn.py:210-217
+ *   bevr_attn_fwd/bwd_*     model/SCA_deform_attn.py:331-413, model/TSA_deform_attn.py:245-333
+ *                           (QK^T*scale + bilinear RPE bias + softmax + PV, never materialised)
+ *   bevr_corr_fwd/bwd       train.py:554 (2 - 2 cam map^T) and the pairwise distance inside
+ *                           loss/contrastive_loss.py:10-19 / loss/lift_loss.py:13-22
+ */
+#ifndef BEVRENDER_HIP_H
+#define BEVRENDER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEVR_ABI_VERSION 1
+
+enum {
+  BEVR_OK = 0,
+  BEVR_E_NULL = -1,      /* a required pointer is NULL */
+  BEVR_E_SHAPE = -2,     /* a dimension violates the contract below */
+  BEVR_E_PRECISION = -3, /* unknown precision code */
+  BEVR_E_ALIGN = -4      /* a pointer is not 16-byte aligned */
+};
+
+enum { BEVR_PREC_F32 = 0, BEVR_PREC_BF16 = 1 };
+
+int bevr_abi_version(void);
+/* Human-readable text for a BEVR_E_* code (static storage). */
+const char* bevr_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention core geometry shared by the three attention kernels.
+ *
+ * Queries are the S x S BEV grid.  The kernels index them column-major with the rows of a column
+ * padded to Sp = 32*ceil(S/32): packed query index  mq = j*Sp + i  (i = BEV row, j = BEV column),
+ * Mp = S*Sp.  Rows i >= S are padding (zero on input, ignored on output).
+ * Keys: N real keys padded to Np (multiple of 64); keys >= N are masked inside the kernels.
+ * head_dim is fixed at 32 (the reference's dims/heads always give 32; smaller heads are zero-padded
+ * by the caller).  heads % groups == 0; the heads of one group share key positions.
+ *
+ * Relative-position bias: the reference samples rpe_table[h, Ht=2S-1, Wt] bilinearly at
+ *   ty = i + a_n,         a_n = (1 - py_n) * (S-1)/2
+ *   tx = j * rx + b_n,    b_n = (1 - px_n) * (Wt-1)/4,   rx = (Wt-1) / (2(S-1))
+ * (algebraically identical to grid_sample(align_corners=True) of (q_grid - pos)/2).
+ * The table is handed over transposed, zero-padded and pair-packed:
+ *   table_pair[h][Wp][Hp][2] = ( T2[y - y_off][x - x_off], T2[y + 1 - y_off][x - x_off] ),  T2 = T * log2(e),
+ * zero outside the real table, with  y_off = Sp + 2, Hp = Ht + 2*Sp + 4,
+ * x_off = (Wt-1)/2 + 4, Wp = 2*Wt + 8  (bevr_attn_table_dims computes them).
+ * Keys carry key_a[n] = a_n, key_b[n] = b_n (float, any value; the kernels clamp to the padded range,
+ * where every tap is zero exactly as grid_sample's zero padding).
+ * Q is pre-multiplied by head_dim^-0.5 * log2(e); logits and LSE are in log2 units.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct bevr_attn_desc {
+  int32_t n_prob;    /* B' = batch * views: independent softmax problems per head            */
+  int32_t q_div;     /* query batch index = prob / q_div (views of one sample share the query) */
+  int32_t heads;     /* h                                                                    */
+  int32_t groups;    /* g                                                                    */
+  int32_t S;         /* BEV side                                                             */
+  int32_t Sp;        /* padded rows per column, 32*ceil(S/32)                                */
+  int32_t N;         /* real keys                                                            */
+  int32_t Np;        /* padded keys, multiple of 64                                          */
+  int32_t Ht, Wt;    /* rpe table height (must equal 2S-1) and width                         */
+  int32_t Hp, Wp;    /* padded table dims                                                    */
+  int32_t y_off, x_off;
+  int32_t precision; /* BEVR_PREC_F32: exact-f32 MFMA; BEVR_PREC_BF16: bf16 operands, f32 accumulate */
+  int32_t reserved;
+} bevr_attn_desc;
+
+/* Fill Sp, Hp, Wp, y_off, x_off from S, Wt.  Returns 0 or BEVR_E_SHAPE. */
+int bevr_attn_table_dims(bevr_attn_desc* d);
+
+/* Forward.  Element type E = float (F32) or bf16 (BF16).
+ *   Q   [n_prob/q_div][heads][Mp][32]  E     K  [n_prob][heads][Np][32] E
+ *   Vt  [n_prob][heads][32][Np] E, keys permuted inside each aligned block of 32: the key with
+ *       in-block index r is stored at position (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1)
+ *       (bits 2 and 3 swapped) -- the order the MFMA consumes the P accumulator in.
+ *   key_a, key_b [n_prob*groups][Np] float      table_pair as above, float
+ *   O   [n_prob][heads][Mp][32] float (normalised)   LSE [n_prob][heads][Mp] float (log2 units) */
+int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* Vt,
+                  const float* key_a, const float* key_b, const float* table_pair,
+                  float* O, float* LSE, void* stream);
+
+/* Backward, query side (same tiling as the forward):  dQ [like Q, float] and the table gradient
+ *   dtable [heads][Wp][Hp+1] float, transposed/padded like table_pair but one value per entry;
+ *   it is ACCUMULATED into (caller zeroes it).
+ *   V  [n_prob][heads][Np][32] E (row layout), Kt [like Vt] E, dO [n_prob][heads][Mp][32] E,
+ *   delta [n_prob][heads][Mp] float = rowsum(dO * O).
+ *   All gradients are with respect to the log2-domain logits' inputs as handed in (Q pre-scaled,
+ *   table pre-multiplied): the caller's autograd undoes the scaling. */
+int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
+                    const float* key_a, const float* key_b, const float* table_pair,
+                    const void* dO, const float* LSE, const float* delta,
+                    float* dQ, float* dtable, void* stream);
+
+/* Backward, key side:  dK, dV [n_prob][heads][Np][32] float, dkey_a, dkey_b [n_prob*groups][Np] float
+ *   (dkey_* are ACCUMULATED over the heads of a group; caller zeroes them).
+ *   Qt, dOt: [..][heads][32][Mp] E with the same in-32 permutation as Vt (over the packed query index). */
+int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
+                    const float* key_a, const float* key_b, const float* table_pair,
+                    const void* dO, const void* dOt, const float* LSE, const float* delta,
+                    float* dK, float* dV, float* dkey_a, float* dkey_b, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bilinear feature sampling, align_corners=True, zero padding (grid_sample semantics).
+ *   feat [nb][Hi][Wi][C] float (channels-last)     pos [nb][N][2] float, (y, x) in [-1, 1] units
+ *   out  [nb][N][C] float
+ * backward: dfeat [nb][Hi][Wi][C] ACCUMULATED (caller zeroes), dpos [nb][N][2] written.
+ * C must be a multiple of 4 and <= 1024.
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_sample_fwd(const float* feat, const float* pos, float* out,
+                    int nb, int Hi, int Wi, int C, int N, void* stream);
+int bevr_sample_bwd(const float* feat, const float* pos, const float* dout, float* dfeat, float* dpos,
+                    int nb, int Hi, int Wi, int C, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BEV pillar grid -> camera pixels (model/bev_cmr_proj.py:61-113).
+ *   points_3d [4][P] float homogeneous IMU-frame points
+ *   cam_inv   [ncam][4][4] float = inverse(imu_to_cam)       Kmat [ncam][3][3] float (already rescaled)
+ *   out       [ncam][2][P] float, (x, y) normalised to [-1, 1]; points whose int-truncated pixel is
+ *             outside [0, W-1) x [0, H-1) are pinned to pixel (0, 0) -> (-1, -1).
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_project_bev_grid(const float* points_3d, const float* cam_inv, const float* Kmat, float* out,
+                          int ncam, int P, int img_w, int img_h, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ground <-> aerial correlation: D[i][j] = 2 - 2 * <cam_i, map_j>  (train.py:554) on raw or
+ * L2-normalised rows.   cam [n][E], map [m][E] float; D [n][m] float.
+ *   normalize != 0: rows are L2-normalised first (the LpDistance(normalize_embeddings=True) of the
+ *   retrieval losses); inv_norm_cam [n], inv_norm_map [m] receive 1/||row|| for the backward.
+ * backward: dcam [n][E], dmap [m][E] written from dD [n][m].
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_corr_fwd(const float* cam, const float* map, float* D, float* inv_norm_cam, float* inv_norm_map,
+                  int n, int m, int E, int normalize, void* stream);
+int bevr_corr_bwd(const float* cam, const float* map, const float* D, const float* dD,
+                  const float* inv_norm_cam, const float* inv_norm_map, float* dcam, float* dmap,
+                  int n, int m, int E, int normalize, void* stream);
+/* Rank of the diagonal within its column (train.py:559-563): rank[k] = #{ i : D[i][k] < D[k][k] }. */
+int bevr_recall_rank(const float* D, int32_t* rank, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVRENDER_HIP_H */

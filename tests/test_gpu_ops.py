@@ -1,0 +1,168 @@
+"""Parity of the HIP kernels (through the C ABI) with the CPU oracle.  Needs a real MI355X."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bevrender_amd import _lib, ops
+from oracle import bevrender_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda"
+
+# tolerances: F32 = exact-f32 MFMA, differences are summation order + the algebraic bias reformulation;
+# BF16 = bf16 operands (Q, K, V, P, dO, dS), f32 accumulation.
+TOL = {_lib.PREC_F32: dict(rtol=2e-4, atol=2e-5), _lib.PREC_BF16: dict(rtol=4e-2, atol=2e-2)}
+
+
+def rel_err(got, want):
+    return (got - want).abs().max().item() / (want.abs().max().item() + 1e-12)
+
+
+def _core_problem(B, V, C, h, g, S, D, N, seed, spread=1.1):
+    gen = torch.Generator().manual_seed(seed)
+    query = torch.randn(B, C, S, S, generator=gen)
+    k = torch.randn(B * V, N, C, generator=gen)
+    v = torch.randn(B * V, N, C, generator=gen)
+    pos = (torch.rand(B * V * g, N, 2, generator=gen) * 2 - 1) * spread
+    pos[0, 0] = torch.tensor([-7.0, 9.0])
+    table = torch.randn(h, 2 * S - 1, 2 * S * D - 1, generator=gen) * 0.3
+    return query, k, v, pos, table
+
+
+def _oracle_core(query, k, v, pos, table, h, g, V):
+    B, C, S, _ = query.shape
+    c = C // h
+    Bp, N, _ = k.shape
+    outs = []
+    for bp in range(Bp):
+        q = query[bp // V].reshape(h, c, S * S)
+        kk = k[bp].reshape(N, h, c).permute(1, 2, 0)
+        vv = v[bp].reshape(N, h, c).permute(1, 2, 0)
+        o = O.attention_core(q, kk, vv, pos[bp * g:(bp + 1) * g], table, S, S, g, c ** -0.5)
+        outs.append(o.reshape(C, S * S).t())
+    return torch.stack(outs, 0)
+
+
+CORE_CFGS = [
+    # B, V, C, h, g, S, D, N
+    (1, 1, 64, 2, 1, 8, 1, 64),
+    (2, 1, 16, 2, 1, 8, 3, 96),
+    (1, 2, 16, 4, 2, 6, 2, 50),
+    (1, 1, 64, 2, 1, 10, 5, 70),
+    (1, 3, 64, 2, 1, 34, 2, 300),     # two row blocks, ragged columns, several views
+]
+
+
+@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16])
+@pytest.mark.parametrize("cfg", CORE_CFGS)
+def test_attention_core_forward_backward(cfg, prec):
+    B, V, C, h, g, S, D, N = cfg
+    query, k, v, pos, table = _core_problem(B, V, C, h, g, S, D, N, seed=sum(cfg))
+    ins_cpu = [t.clone().requires_grad_(True) for t in (query, k, v, pos, table)]
+    want = _oracle_core(*ins_cpu, h, g, V)
+    cot = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+    want.backward(cot)
+
+    ins_gpu = [t.clone().to(DEV).requires_grad_(True) for t in (query, k, v, pos, table)]
+    got = ops.attention_core(*ins_gpu, heads=h, groups=g, views=V, precision=prec)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), **TOL[prec])
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    names = ["query", "k", "v", "pos", "table"]
+    lim = 5e-4 if prec == _lib.PREC_F32 else 5e-2
+    for n, a, b in zip(names, ins_gpu, ins_cpu):
+        e = rel_err(a.grad.cpu(), b.grad)
+        assert e < lim, f"grad {n}: rel err {e:.3e}"
+
+
+def test_attention_rows_are_a_convex_combination_at_scale():
+    """Size-independent property at a BEV side the oracle cannot materialise (S=100, N=25000):
+    V = const channel pattern -> output equals that pattern for every query (softmax rows sum to 1)."""
+    B, V, C, h, S, D = 1, 1, 64, 2, 100, 5
+    N = (S // 2) * S * D
+    gen = torch.Generator().manual_seed(3)
+    query = torch.randn(B, C, S, S, generator=gen).to(DEV)
+    k = torch.randn(B, N, C, generator=gen).to(DEV)
+    pat = torch.randn(C, generator=gen)
+    v = pat[None, None, :].expand(B, N, C).contiguous().to(DEV)
+    pos = (torch.rand(B, N, 2, generator=gen) * 2 - 1).to(DEV)
+    table = (torch.randn(h, 2 * S - 1, 2 * S * D - 1, generator=gen) * 0.3).to(DEV)
+    out = ops.attention_core(query, k, v, pos, table, heads=h, groups=1, views=1, precision=_lib.PREC_F32)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), pat[None, None, :].expand_as(out).numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 6, 10, 96, 1), (2, 16, 6, 10, 96, 2), (1, 64, 16, 44, 1000, 1)])
+def test_sample_features_matches_grid_sample(shape):
+    B, C, Hi, Wi, N, g = shape
+    gen = torch.Generator().manual_seed(5)
+    feat = torch.randn(B, C, Hi, Wi, generator=gen)
+    pos = (torch.rand(B * g, N, 2, generator=gen) * 2 - 1) * 1.2
+    pos[0, :8] = torch.tensor([[-1., -1.], [1., 1.], [-1., 1.], [0., 0.], [1.5, 0.], [0., -1.5], [.999, .999], [3., 3.]])
+    fc, pc = feat.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    want = F.grid_sample(fc.reshape(B * g, C // g, Hi, Wi), pc[:, None, :, (1, 0)], mode="bilinear",
+                         align_corners=True).reshape(B, C, N).permute(0, 2, 1)
+    cot = torch.randn(want.shape, generator=gen)
+    want.backward(cot)
+    fg, pg = feat.clone().to(DEV).requires_grad_(True), pos.clone().to(DEV).requires_grad_(True)
+    got = ops.sample_features(fg, pg, g)
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(fg.grad.cpu().numpy(), fc.grad.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(pg.grad.cpu().numpy(), pc.grad.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "proj_*.npz"))))
+def test_projector_matches_reference_golden(name):
+    from bevrender_amd.model.SCA import pillar_grid
+    from bevrender_amd.model.bev_cmr_proj import BEV2CameraProjector
+    z = np.load(os.path.join(GOLDEN, name))
+    S, D, X, Y, Z, zs, iw, ih, ow, oh = z["cfg"]
+    proj = BEV2CameraProjector(imu_to_rgb={0: list(z["imu_to_rgb"])}, K={0: [k.copy() for k in z["K"]]},
+                               vehicle_type_code=0, img_width=int(iw), img_height=int(ih), ori_img_width=int(ow),
+                               ori_img_height=int(oh), device=DEV)
+    pts = pillar_grid({"X": X, "Y": Y, "Z": Z}, int(S), int(D), float(zs))
+    got = torch.stack(proj.bev_grid_to_camera(pts)[0], 0).cpu().numpy()
+    want = z["points_2d"]
+    # the in-bound decision uses an int truncation; a point within float rounding of a pixel boundary
+    # may legitimately flip: allow a vanishing fraction, everything else must agree to 1e-5.
+    close = np.isclose(got, want, rtol=1e-5, atol=1e-5).all(axis=1)
+    assert close.mean() > 0.999, f"{(~close).sum()} of {close.size} points differ"
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_pairwise_corr_and_recall(normalize):
+    gen = torch.Generator().manual_seed(9)
+    n, m, E = 8, 8, 64 * 28 * 28
+    cam = torch.randn(n, E, generator=gen)
+    mp = cam + 0.8 * torch.randn(m, E, generator=gen)
+    cc, mc = cam.clone().double().requires_grad_(True), mp.clone().double().requires_grad_(True)
+    a, b = (F.normalize(cc, dim=1), F.normalize(mc, dim=1)) if normalize else (cc, mc)
+    want = O.pairwise_corr(a, b)
+    cot = torch.randn(n, m, generator=gen)
+    want.backward(cot.double())
+    cg, mg = cam.clone().to(DEV).requires_grad_(True), mp.clone().to(DEV).requires_grad_(True)
+    got = ops.pairwise_corr(cg, mg, normalize)
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    scale = want.abs().max().item()
+    assert (got.detach().cpu().double() - want.detach()).abs().max().item() < 2e-5 * max(scale, 1.0)
+    assert rel_err(cg.grad.cpu().double(), cc.grad) < 1e-4
+    assert rel_err(mg.grad.cpu().double(), mc.grad) < 1e-4
+
+
+def test_recall_rank_matches_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "recall.npz"))
+    for tag in ("a", "b"):
+        cam, mp = torch.tensor(z[f"cam_{tag}"]).float().to(DEV), torch.tensor(z[f"map_{tag}"]).float().to(DEV)
+        D = ops.pairwise_corr(cam, mp, False)
+        rank = ops.recall_rank(D).cpu().numpy()
+        got = tuple(float((rank < i).mean() * 100.0) for i in (1, 5, 10))
+        np.testing.assert_allclose(np.array(got), z[f"recall_{tag}"], atol=1e-9)

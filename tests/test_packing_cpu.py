@@ -1,0 +1,93 @@
+"""CPU checks of the host logic: packed layouts + the kernels' algebraic reformulation of the RPE bias
+(emulated in torch, float64) against the oracle's materialised formulation."""
+import numpy as np
+import pytest
+import torch
+
+from bevrender_amd import ops
+from oracle import bevrender_oracle as O
+from tests.kernel_emul import emul_attn_fwd
+
+
+def _problem(B, V, C, h, g, S, D, N, seed, spread=1.2, dtype=torch.float64):
+    gen = torch.Generator().manual_seed(seed)
+    query = torch.randn(B, C, S, S, generator=gen, dtype=dtype)
+    k = torch.randn(B * V, N, C, generator=gen, dtype=dtype)
+    v = torch.randn(B * V, N, C, generator=gen, dtype=dtype)
+    pos = (torch.rand(B * V * g, N, 2, generator=gen, dtype=dtype) * 2 - 1) * spread
+    Wt = 2 * S * D - 1
+    table = torch.randn(h, 2 * S - 1, Wt, generator=gen, dtype=dtype) * 0.3
+    return query, k, v, pos, table
+
+
+def _oracle_core(query, k, v, pos, table, h, g, V):
+    B, C, S, _ = query.shape
+    c = C // h
+    outs = []
+    Bp, N, _ = k.shape
+    for bp in range(Bp):
+        b = bp // V
+        q = query[b:b + 1].reshape(h, c, S * S)
+        kk = k[bp].reshape(N, h, c).permute(1, 2, 0)
+        vv = v[bp].reshape(N, h, c).permute(1, 2, 0)
+        o = O.attention_core(q, kk, vv, pos[bp * g:(bp + 1) * g], table, S, S, g, c ** -0.5)  # (h, c, M)
+        outs.append(o.reshape(C, S * S).t())
+    return torch.stack(outs, 0)
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, V, C, h, g, S, D, N
+    (1, 1, 16, 2, 1, 8, 1, 64),      # TSA-like
+    (2, 1, 16, 2, 1, 8, 3, 96),      # SCA fixture shape
+    (1, 2, 16, 4, 2, 6, 2, 50),      # views + groups + ragged N, S not multiple of anything
+    (1, 1, 64, 2, 1, 10, 5, 70),     # full head width 32, N not a multiple of 64
+])
+def test_packed_formulation_equals_reference_formulation(cfg):
+    B, V, C, h, g, S, D, N = cfg
+    query, k, v, pos, table = _problem(B, V, C, h, g, S, D, N, seed=sum(cfg))
+    # a few keys far outside, a few exactly on the border
+    pos[0, 0] = torch.tensor([-7.0, 9.0], dtype=pos.dtype)
+    pos[0, 1] = torch.tensor([1.0, -1.0], dtype=pos.dtype)
+    pos[0, 2] = torch.tensor([-1.0, 1.0], dtype=pos.dtype)
+    want = _oracle_core(query, k, v, pos, table, h, g, V)
+
+    geom = ops.AttnGeom(n_prob=B * V, q_div=V, heads=h, groups=g, S=S, N=N, Wt=table.shape[-1], precision=0)
+    Qp = ops.pack_query(query, h)
+    Kp, Vp = ops.pack_keys(k, h), ops.pack_keys(v, h)
+    a, b = ops.key_coords(pos, S, geom.Wt, geom.Np)
+    Tt = ops.pack_table(table, geom)
+    assert Qp.shape == (B, h, geom.Mp, 32) and Kp.shape == (B * V, h, geom.Np, 32)
+    assert Tt.shape == (h, geom.Wp, geom.Hp + 1)
+    Op, _ = emul_attn_fwd(Qp, Kp, Vp, a, b, Tt, geom)
+    got = ops.unpack_out(Op, S, C // h)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-9, atol=1e-10)
+
+
+def test_geometry_matches_header_rules():
+    g = ops.AttnGeom(n_prob=24, q_div=6, heads=2, groups=1, S=200, N=100000, Wt=1999, precision=1)
+    assert (g.Sp, g.Mp, g.Np) == (224, 200 * 224, 100032)
+    assert (g.Ht, g.Hp, g.y_off) == (399, 399 + 448 + 4, 226)
+    assert (g.x_off, g.Wp) == (999 + 4, 1999 + 1998 + 9)
+    assert g.Hp * g.Wp * 8 < 2 ** 31
+
+
+def test_perm32_is_involution_and_matches_mfma_order():
+    p = [ops.perm32(r) for r in range(32)]
+    assert sorted(p) == list(range(32))
+    assert [ops.perm32(x) for x in p] == list(range(32))
+    # position 16 s + 8 hi + j must hold accumulator row crow(8 s + j, hi) = 16 s + 8 (j >> 2) + 4 hi + (j & 3)
+    for s in range(2):
+        for hi in range(2):
+            for j in range(8):
+                assert ops.perm32(16 * s + 8 * hi + j) == 16 * s + 8 * (j >> 2) + 4 * hi + (j & 3)
+    idx = ops.perm_index(64, "cpu")
+    assert idx[:32].tolist() == p and idx[32:].tolist() == [32 + x for x in p]
+
+
+def test_pack_unpack_roundtrip():
+    torch.manual_seed(0)
+    S, h, c = 6, 2, 8
+    x = torch.randn(3, h * c, S, S)
+    Qp = ops.pack_query(x, h) / (c ** -0.5 * ops.LOG2E)
+    back = ops.unpack_out(Qp, S, c)                         # (B, S*S, C) rows i*S + j
+    np.testing.assert_allclose(back.numpy(), x.reshape(3, h * c, S * S).permute(0, 2, 1).numpy(), rtol=1e-6)

@@ -34,6 +34,9 @@ def check(mod, z, out, inputs, prec):
     out.backward(torch.tensor(z["cot"]).to(DEV))
     torch.cuda.synchronize()
     lim = 1e-3 if f32 else 8e-2
+    # absolute floor: some reference gradients are pure rounding noise (proj_k.bias shifts every logit of a
+    # query equally, so its true gradient is 0)
+    floor = (2e-5 if f32 else 2e-3) * max(np.abs(v).max() for k, v in z.items() if k.startswith("grad_"))
     for k, v in z.items():
         if k.startswith("grad_param."):
             g = dict(mod.named_parameters())[k[len("grad_param."):]].grad
@@ -44,7 +47,7 @@ def check(mod, z, out, inputs, prec):
         else:
             continue
         err = np.abs(g - v).max() / (np.abs(v).max() + 1e-12)
-        assert err < lim, f"{k}: rel err {err:.3e}"
+        assert np.abs(g - v).max() <= lim * np.abs(v).max() + floor, f"{k}: rel err {err:.3e}"
 
 
 @pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16])

@@ -10,6 +10,10 @@ import os
 import subprocess
 import threading
 
+import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: torch bundles its own HIP runtime
+# (libamdhip64.so.7); loading ours first would bind the process to /opt/rocm's copy and torch would then fail with
+# "no ROCm-capable device".  With torch loaded first both share torch's runtime.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbevrender_hip.so")
 CSRC = os.path.join(_HERE, "csrc")

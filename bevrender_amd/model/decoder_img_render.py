@@ -1,0 +1,76 @@
+"""Render decoder: BEV features -> (B, 3, 224, 224) aerial-like image (dense convs: left to MIOpen).
+Counterpart of the reference's model/decoder_img_render.py:4-93 with its parameter names; defined, like
+the reference, for BEV side 14 / 28 / 56 only."""
+import torch.nn as nn
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c, eps=1e-05, momentum=0.1, affine=True, track_running_stats=True)
+
+
+class BasicBlock(nn.Module):
+    """Four 3x3 conv + BN pairs and one ReLU (no skip connection, as in the reference :95-180)."""
+
+    def __init__(self, in_channel, hidden_dim, out_channel, downsample_or_not):
+        super().__init__()
+        self.basic_block = nn.Sequential(
+            nn.Conv2d(in_channel, hidden_dim, 3, 1, 1, bias=False), _bn(hidden_dim),
+            nn.Conv2d(hidden_dim, hidden_dim, 3, 1, 1, bias=False), _bn(hidden_dim),
+            nn.Conv2d(hidden_dim, hidden_dim, 3, 1, 1, bias=False), _bn(hidden_dim),
+            nn.Conv2d(hidden_dim, out_channel, 3, 1, 1, bias=False), _bn(hidden_dim),
+            nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.basic_block(x)
+
+
+class UpSampleLayer1(nn.Module):
+    def __init__(self, in_channel, hidden_dim, out_channel, scale, mode="bilinear"):
+        super().__init__()
+        self.upsample1_block = nn.Sequential(
+            nn.Upsample(scale_factor=scale, mode=mode),
+            nn.Conv2d(in_channel, hidden_dim, 3, 1, 1, bias=False), nn.BatchNorm2d(hidden_dim),
+            nn.Conv2d(hidden_dim, out_channel, 3, 1, 1, bias=False), nn.BatchNorm2d(out_channel),
+            nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.upsample1_block(x)
+
+
+class UpSampleLayer2(nn.Module):
+    def __init__(self, in_channel, hidden_dim, out_channel, scale, mode="bilinear"):
+        super().__init__()
+        self.upsample2_block = nn.Sequential(
+            nn.Upsample(scale_factor=scale, mode=mode),
+            nn.Conv2d(in_channel, hidden_dim, 3, 1, 1, bias=False), nn.BatchNorm2d(hidden_dim),
+            nn.Conv2d(hidden_dim, out_channel, 1, 1, bias=False), nn.Sigmoid())
+
+    def forward(self, x):
+        return self.upsample2_block(x)
+
+
+class BEVImageRenderDecoder(nn.Module):
+    def __init__(self, bev_spatial_dim, model_dim=256, hid_dim=64, logger=None, use_wandb=False):
+        super().__init__()
+        self.logger, self.use_wandb = logger, use_wandb
+        md = model_dim
+        self.decoder_block0 = nn.Sequential(nn.Conv2d(md, hid_dim, 7, 2, 3, bias=False), _bn(64), nn.ReLU(inplace=True))
+        self.decoder_block1 = BasicBlock(hid_dim, hid_dim, hid_dim, False)
+        self.decoder_block2 = BasicBlock(hid_dim, hid_dim * 2, hid_dim * 2, True)
+        self.decoder_block3 = BasicBlock(hid_dim * 2, md, md, True)
+        self.upsample_block1 = UpSampleLayer1(md, md // 2, md // 2, scale=2.0)
+        self.upsample_block2 = UpSampleLayer1(md // 2, md // 4, md // 4, scale=2.0)
+        self.upsample_block4 = UpSampleLayer1(md // 4, md // 4, md // 4, scale=2.0)
+        self.upsample_block5 = UpSampleLayer1(md // 4, md // 4, md // 4, scale=2.0)
+        self.upsample_block3 = UpSampleLayer2(md // 4, md // 8, 3, scale=2.0)
+        head = [self.decoder_block0, self.decoder_block1, self.decoder_block2, self.decoder_block3,
+                self.upsample_block1, self.upsample_block2]
+        extra = {56: [], 28: [self.upsample_block4], 14: [self.upsample_block4, self.upsample_block5]}
+        if bev_spatial_dim not in extra:
+            raise ValueError("the render decoder is defined for BEV side 14, 28 or 56 only (as in the reference)")
+        self.decoder_layers = nn.ModuleList(head + extra[bev_spatial_dim] + [self.upsample_block3])
+
+    def forward(self, x):
+        for layer in self.decoder_layers:
+            x = layer(x)
+        return x

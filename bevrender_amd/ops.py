@@ -145,6 +145,48 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _KernelTimer:
+    """Optional per-kernel device timing with events recorded on the stream the kernels are launched on
+    (bench.py's roofline leg).  Off by default: no events, no overhead."""
+
+    def __init__(self):
+        self.on = False
+        self.records = []
+
+    def start(self):
+        self.on, self.records = True, []
+
+    def stop(self):
+        self.on = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            r = out.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0})
+            r["ms"] += e0.elapsed_time(e1)
+            r["n"] += 1
+            r["flops"] += flops
+        self.records = []
+        return out
+
+    def run(self, name, flops, fn, *args):
+        if not self.on:
+            return fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.records.append((name, flops, e0, e1))
+        return rc
+
+
+KERNEL_TIMER = _KernelTimer()
+
+
+def _attn_flops(geom, n_matmul):
+    """algorithmic MFMA flops of one attention launch: 2 flop/MAC x head_dim 32 x query-key pairs."""
+    return 2.0 * HEAD_DIM * geom.n_prob * geom.heads * (geom.S * geom.S) * geom.N * n_matmul
+
+
 def _edtype(precision: int):
     return torch.bfloat16 if precision == _lib.PREC_BF16 else torch.float32
 
@@ -171,8 +213,9 @@ class _AttnCore(torch.autograd.Function):
         O = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=Qp.device, dtype=torch.float32)
         LSE = torch.empty(geom.n_prob, geom.heads, geom.Mp, device=Qp.device, dtype=torch.float32)
         d = geom.desc()
-        _lib.check(L.bevr_attn_fwd(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Vt), _ptr(key_a), _ptr(key_b),
-                                   _ptr(pair), _ptr(O), _ptr(LSE), _stream()), "bevr_attn_fwd")
+        _lib.check(KERNEL_TIMER.run("bevr_attn_fwd", _attn_flops(geom, 2), L.bevr_attn_fwd, C.byref(d), _ptr(Qe),
+                                    _ptr(Ke), _ptr(Vt), _ptr(key_a), _ptr(key_b), _ptr(pair), _ptr(O), _ptr(LSE),
+                                    _stream()), "bevr_attn_fwd")
         ctx.geom = geom
         ctx.save_for_backward(Qe, Ke, Ve, key_a, key_b, pair, O, LSE)
         return O
@@ -191,9 +234,9 @@ class _AttnCore(torch.autograd.Function):
         dQ = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
         dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
         Kt = _perm_t(Ke)
-        _lib.check(L.bevr_attn_bwd_q(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_a), _ptr(key_b),
-                                     _ptr(pair), _ptr(dOe), _ptr(LSE), _ptr(delta), _ptr(dQ), _ptr(dT), _stream()),
-                   "bevr_attn_bwd_q")
+        _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(geom, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
+                                    _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_a), _ptr(key_b), _ptr(pair), _ptr(dOe),
+                                    _ptr(LSE), _ptr(delta), _ptr(dQ), _ptr(dT), _stream()), "bevr_attn_bwd_q")
         del Kt
         dK = torch.empty(geom.n_prob, geom.heads, geom.Np, HEAD_DIM, device=dev, dtype=torch.float32)
         dV = torch.empty_like(dK)
@@ -201,9 +244,10 @@ class _AttnCore(torch.autograd.Function):
         db = torch.zeros_like(key_b)
         Qt = _perm_t(Qe)
         dOt = _perm_t(dOe)
-        _lib.check(L.bevr_attn_bwd_k(C.byref(d), _ptr(Qe), _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(key_a), _ptr(key_b),
-                                     _ptr(pair), _ptr(dOe), _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(dK), _ptr(dV),
-                                     _ptr(da), _ptr(db), _stream()), "bevr_attn_bwd_k")
+        _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_k", _attn_flops(geom, 4), L.bevr_attn_bwd_k, C.byref(d), _ptr(Qe),
+                                    _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(key_a), _ptr(key_b), _ptr(pair), _ptr(dOe),
+                                    _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(dK), _ptr(dV), _ptr(da), _ptr(db),
+                                    _stream()), "bevr_attn_bwd_k")
         if geom.q_div > 1:  # the views of one sample share the query: sum their query gradients
             dQ = dQ.reshape(geom.n_prob // geom.q_div, geom.q_div, geom.heads, geom.Mp, HEAD_DIM).sum(1)
         return dQ, dK, dV, da, db, dT, None
@@ -244,8 +288,8 @@ class _Sample(torch.autograd.Function):
         nb, Hi, Wi, Cc = feat.shape
         N = pos.shape[1]
         out = torch.empty(nb, N, Cc, device=feat.device, dtype=torch.float32)
-        _lib.check(_lib.lib().bevr_sample_fwd(_ptr(feat), _ptr(pos), _ptr(out), nb, Hi, Wi, Cc, N, _stream()),
-                   "bevr_sample_fwd")
+        _lib.check(KERNEL_TIMER.run("bevr_sample_fwd", 0.0, _lib.lib().bevr_sample_fwd, _ptr(feat), _ptr(pos),
+                                    _ptr(out), nb, Hi, Wi, Cc, N, _stream()), "bevr_sample_fwd")
         ctx.save_for_backward(feat, pos)
         return out
 
@@ -257,8 +301,9 @@ class _Sample(torch.autograd.Function):
         dout = dout.contiguous()
         dfeat = torch.zeros_like(feat)
         dpos = torch.empty_like(pos)
-        _lib.check(_lib.lib().bevr_sample_bwd(_ptr(feat), _ptr(pos), _ptr(dout), _ptr(dfeat), _ptr(dpos), nb, Hi, Wi,
-                                              Cc, N, _stream()), "bevr_sample_bwd")
+        _lib.check(KERNEL_TIMER.run("bevr_sample_bwd", 0.0, _lib.lib().bevr_sample_bwd, _ptr(feat), _ptr(pos),
+                                    _ptr(dout), _ptr(dfeat), _ptr(dpos), nb, Hi, Wi, Cc, N, _stream()),
+                   "bevr_sample_bwd")
         return dfeat, dpos
 
 

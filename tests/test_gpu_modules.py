@@ -101,3 +101,27 @@ def test_sca_multi_view_is_the_composition_of_single_views():
     m = m.to(DEV)
     got, _ = m(x.to(DEV), query.to(DEV), ref.to(DEV), {}, False)
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.numpy(), rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.parametrize("prec", [_lib.PREC_F32])
+def test_encoder_layer_matches_reference(prec):
+    """One full EncoderLayer (LPU, shared LN, TSA, MLP, LPU, SCA with the projected pillar grid, MLP), train
+    mode, forward + all gradients, against the reference's own EncoderLayer (tests/golden/enclayer.npz)."""
+    from bevrender_amd.model.bev_cmr_proj import BEV2CameraProjector
+    from bevrender_amd.model.encoder import EncoderLayer
+    z = load("enclayer.npz")
+    B, C, S, D, h, X, Y, Z = [int(v) for v in z["cfg"]]
+    proj = BEV2CameraProjector(imu_to_rgb={0: list(z["imu_to_rgb"])}, K={0: [k.copy() for k in z["K"]]},
+                               vehicle_type_code=0, img_width=128, img_height=128, ori_img_width=128,
+                               ori_img_height=128, device=DEV)
+    layer = EncoderLayer(bev_bound={"X": X, "Y": Y, "Z": Z}, bev2cmr_projector=proj, n_views=1, bev_feat_shape=S,
+                         bev_depth_dim=D, z_shift=-1.0, dim_embed=C, expansion=4, stage_idx=0, n_groups=1, n_heads=h,
+                         stride=1, kernel_size=3, batch_size=B, scale_offset_range=True, drop_path_rate=0.0,
+                         precision=prec).to(DEV)
+    load_params(layer, z)
+    layer.train()
+    bev_query = torch.tensor(z["bev_query"]).to(DEV).requires_grad_(True)
+    prev_bev = torch.tensor(z["prev_bev"]).to(DEV).requires_grad_(True)
+    img_feat = torch.tensor(z["img_feat"]).to(DEV).requires_grad_(True)
+    out, _ = layer(bev_query, img_feat, prev_bev, torch.zeros(B, 2, 3, device=DEV), torch.tensor(0), {}, False)
+    check(layer, z, out, {"bev_query": bev_query, "prev_bev": prev_bev, "img_feat": img_feat}, prec)

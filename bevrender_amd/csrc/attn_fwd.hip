@@ -7,18 +7,19 @@
 //   * softmax statistics of a query are lane-local (16 registers + one cross-half exchange);
 //   * P^T is already the B operand of O^T[ch][q] += V^T[ch][key] P^T[key][q]  (no LDS transpose);
 //   * the lanes of a tile are 32 consecutive BEV rows i of one BEV column j, so with the rpe table
-//     stored transposed (y contiguous) the 4 bilinear taps of the 32 lanes are 2 coalesced 256-B rows.
+//     stored transposed (y contiguous) the bilinear taps of the 32 lanes are consecutive addresses:
+//     conflict-free 8-byte LDS reads from the step's table window (attn_tile.h), or two coalesced
+//     256-byte global rows on the fallback path.
 // Work split: workgroup = 4 waves = one 32-row block x (4*NQ) BEV columns; wave w owns NQ columns;
 // all waves walk the keys together, 64 per step, K / V^T / key constants staged through LDS
-// (double buffered, one barrier per step).  blockIdx is remapped so that all query tiles of one
-// (problem, head) run on one XCD and stream the same K/V through that XCD's L2.
-#include "bevr_common.h"
+// (double buffered).  blockIdx is remapped so that all query tiles of one (problem, head) run on one
+// XCD and stream the same K/V through that XCD's L2.
+#include "attn_tile.h"
 
 namespace {
 
-constexpr int KT = 64;            // keys per step
-constexpr int THREADS = 256;
 constexpr float RESCALE_THR = 8.0f;  // log2 units: lazy running-max update (P <= 2^8)
+constexpr int WIN_COLS = 96;         // window columns held in LDS (x 64 rows x 8 B = 48 KiB)
 
 template <int PREC> struct Lds {
   static constexpr int EB = Elem<PREC>::bytes;
@@ -26,20 +27,24 @@ template <int PREC> struct Lds {
   static constexpr int V_STRIDE = KT * EB + 16;   // bytes per channel row
   static constexpr int K_BYTES = KT * K_STRIDE;
   static constexpr int V_BYTES = 32 * V_STRIDE;
-  static constexpr int C_BYTES = KT * 16;         // KeyC per key
+  static constexpr int C_BYTES = KT * 16 + 32;    // KeyW per key + WinInfo
   static constexpr int BUF = K_BYTES + V_BYTES + C_BYTES;
+  static constexpr int WIN = WIN_COLS * WIN_PITCH * 8;
+  static constexpr int TOTAL = 2 * BUF + WIN;
 };
 
 template <int PREC, int NQ>
-__global__ __launch_bounds__(THREADS) void attn_fwd_kernel(bevr_attn_desc d, const char* __restrict__ Q,
-                                                           const char* __restrict__ K, const char* __restrict__ Vt,
-                                                           const float* __restrict__ key_a,
-                                                           const float* __restrict__ key_b,
-                                                           const char* __restrict__ table_pair,
-                                                           float* __restrict__ O, float* __restrict__ LSE) {
+__global__ __launch_bounds__(THREADS, PREC == BEVR_PREC_BF16 ? 2 : 1) void attn_fwd_kernel(bevr_attn_desc d, const char* __restrict__ Q,
+                                                              const char* __restrict__ K,
+                                                              const char* __restrict__ Vt,
+                                                              const float* __restrict__ key_a,
+                                                              const float* __restrict__ key_b,
+                                                              const char* __restrict__ table_pair,
+                                                              float* __restrict__ O, float* __restrict__ LSE) {
   typedef Lds<PREC> L;
   constexpr int EB = L::EB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* win = smem + 2 * L::BUF;
 
   // ---- which (problem, head, query tile) -------------------------------------------------------
   const int n_rb = d.Sp / 32;
@@ -67,6 +72,9 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(bevr_attn_desc d, con
   const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
   const int Hp8 = d.Hp * 8;
   const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
+  const int j_first = cb * 4 * NQ;
+  const int j_last = min(j_first + 4 * NQ - 1, d.S - 1);
+  const float jrx_lo = (float)j_first * rx, jrx_hi = (float)j_last * rx;
 
   // ---- per-wave query columns -------------------------------------------------------------------
   Frag<PREC> qf[NQ];
@@ -74,13 +82,14 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(bevr_attn_desc d, con
   int jcol[NQ];
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
-    int j = cb * 4 * NQ + wave * NQ + t;
+    int j = j_first + wave * NQ + t;
     jcol[t] = j;
     int jc = j < d.S ? j : d.S - 1;  // columns past the grid: compute on a clamped copy, never stored
     jrx[t] = (float)jc * rx;
     qf[t].load(Qh + ((size_t)jc * d.Sp + i0 + lq) * 32 * EB, hi);
   }
   const int rowoff = (i0 + lq) * 8;
+  const int lq8 = lq * 8;
 
   f32x16 o[NQ];
   float m[NQ], l[NQ];
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(bevr_attn_desc d, con
   constexpr int NCH = KT * KCH_ROW / THREADS;      // chunks per thread for each of K and V (1 or 2)
   static_assert(KT * KCH_ROW % THREADS == 0 && 32 * VCH_ROW == KT * KCH_ROW, "staging shape");
   u32x4 stK[NCH], stV[NCH];
-  KeyC stC;
+  float st_a = 0.f, st_b = 0.f;
   const int n_step = d.Np / KT;
 
   auto stage_load = [&](int step) {
@@ -109,9 +118,9 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(bevr_attn_desc d, con
       int vr = ch / VCH_ROW, vc = ch % VCH_ROW;
       stV[c] = *reinterpret_cast<const u32x4*>(Vh + ((size_t)vr * d.Np + (size_t)step * KT) * EB + vc * 16);
     }
-    if (tid < KT) stC = make_keyc(ka[step * KT + tid], kb[step * KT + tid], d);
+    if (tid < KT) { st_a = ka[step * KT + tid]; st_b = kb[step * KT + tid]; }
   };
-  auto stage_store = [&](int buf) {
+  auto stage_store = [&](int buf, int step) {
     char* base = smem + buf * L::BUF;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -119,24 +128,42 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(bevr_attn_desc d, con
       *reinterpret_cast<u32x4*>(base + (ch / KCH_ROW) * L::K_STRIDE + (ch % KCH_ROW) * 16) = stK[c];
       *reinterpret_cast<u32x4*>(base + L::K_BYTES + (ch / VCH_ROW) * L::V_STRIDE + (ch % VCH_ROW) * 16) = stV[c];
     }
-    if (tid < KT) *reinterpret_cast<KeyC*>(base + L::K_BYTES + L::V_BYTES + tid * 16) = stC;
+    if (tid < KT) {   // exactly wave 0
+      WinInfo wi;
+      KeyW kw = stage_keys(st_a, st_b, step * KT + tid < d.N, d, jrx_lo, jrx_hi, WIN_COLS, wi);
+      *reinterpret_cast<KeyW*>(base + L::K_BYTES + L::V_BYTES + tid * 16) = kw;
+      if (tid == 0) *reinterpret_cast<WinInfo*>(base + L::K_BYTES + L::V_BYTES + KT * 16) = wi;
+    }
   };
 
   stage_load(0);
-  stage_store(0);
+  stage_store(0, 0);
   __syncthreads();
+
+  Region rg;
+  rg.ax0 = -(1 << 28);   // nothing contained: first windowed step anchors
+  rg.ay0 = 0;
 
   for (int step = 0; step < n_step; ++step) {
     const int buf = step & 1;
     const char* base = smem + buf * L::BUF;
     if (step + 1 < n_step) stage_load(step + 1);
+    const WinInfo wi = *reinterpret_cast<const WinInfo*>(base + L::K_BYTES + L::V_BYTES + KT * 16);
+    const bool use_win = wi.ok != 0;   // workgroup-uniform
+    if (use_win && !region_contains(rg, wi, WIN_COLS)) {
+      rg = region_anchor(wi, d, i0, WIN_COLS);
+      load_region(win, tbl, d, rg, i0, WIN_COLS, wave, lane);
+      __syncthreads();
+    }
+    const float ax0_f = (float)rg.ax0;
+    const int drow8 = (wi.amin - rg.ay0) * 8 + lq8;
 
 #pragma unroll
     for (int ks = 0; ks < KT / 32; ++ks) {
       Frag<PREC> kf, vf;
       kf.load(base + (ks * 32 + lq) * L::K_STRIDE, hi);
       load_perm(vf, base + L::K_BYTES + lq * L::V_STRIDE + ks * 32 * EB, hi);
-      const KeyC* kc = reinterpret_cast<const KeyC*>(base + L::K_BYTES + L::V_BYTES) + ks * 32;
+      const KeyW* kc = reinterpret_cast<const KeyW*>(base + L::K_BYTES + L::V_BYTES) + ks * 32;
 
       f32x16 s[NQ];
 #pragma unroll
@@ -147,21 +174,44 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(bevr_attn_desc d, con
       }
 
       // relative-position bias: rows of the tile are keys crow(r, hi); lanes are BEV rows i0 + lq.
+      if (use_win) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const KeyC c = kc[crow(r, hi)];
-        const int ar = c.aoff + rowoff;
+        for (int r = 0; r < 16; ++r) {
+          const KeyW c = kc[crow(r, hi)];
+          const float wy0 = 1.0f - c.fy;
+          const float bl = c.b - ax0_f;
+          const char* wr = win + c.arow8 + drow8;
 #pragma unroll
-        for (int t = 0; t < NQ; ++t) {
-          float tx = jrx[t] + c.b;
-          float xf = floorf(tx);
-          float fx = tx - xf;
-          unsigned off = (unsigned)((int)xf * Hp8 + ar);
-          f32x2 t0 = *reinterpret_cast<const f32x2*>(tbl + off);
-          f32x2 t1 = *reinterpret_cast<const f32x2*>(tbl + off + Hp8);
-          float u0 = t0[0] * c.wy0 + t0[1] * c.fy;
-          float u1 = t1[0] * c.wy0 + t1[1] * c.fy;
-          s[t][r] += u0 + fx * (u1 - u0);
+          for (int t = 0; t < NQ; ++t) {
+            float tx = jrx[t] + bl;
+            float xf = floorf(tx);
+            float fx = tx - xf;
+            const char* p = wr + (int)xf * (WIN_PITCH * 8);
+            f32x2 t0 = *reinterpret_cast<const f32x2*>(p);
+            f32x2 t1 = *reinterpret_cast<const f32x2*>(p + WIN_PITCH * 8);
+            float u0 = t0[0] * wy0 + t0[1] * c.fy;
+            float u1 = t1[0] * wy0 + t1[1] * c.fy;
+            s[t][r] += u0 + fx * (u1 - u0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const KeyW c = kc[crow(r, hi)];
+          const float wy0 = 1.0f - c.fy;
+          const int ar = c.aoff + rowoff;
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) {
+            float tx = jrx[t] + c.b;
+            float xf = floorf(tx);
+            float fx = tx - xf;
+            unsigned off = (unsigned)((int)xf * Hp8 + ar);
+            f32x2 t0 = *reinterpret_cast<const f32x2*>(tbl + off);
+            f32x2 t1 = *reinterpret_cast<const f32x2*>(tbl + off + Hp8);
+            float u0 = t0[0] * wy0 + t0[1] * c.fy;
+            float u1 = t1[0] * wy0 + t1[1] * c.fy;
+            s[t][r] += u0 + fx * (u1 - u0);
+          }
         }
       }
       // mask padded keys (only the last step can hold any)
@@ -200,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void attn_fwd_kernel(bevr_attn_desc d, con
       }
     }
 
-    if (step + 1 < n_step) stage_store(buf ^ 1);
+    if (step + 1 < n_step) stage_store(buf ^ 1, step + 1);
     __syncthreads();
   }
 
@@ -231,7 +281,14 @@ int launch_fwd(const bevr_attn_desc& d, const void* Q, const void* K, const void
   const int n_rb = d.Sp / 32, n_cb = (d.S + 4 * NQ - 1) / (4 * NQ);
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_rb * n_cb;
-  const size_t lds = 2 * Lds<PREC>::BUF;
+  const size_t lds = Lds<PREC>::TOTAL;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<PREC, NQ>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
   hipLaunchKernelGGL((attn_fwd_kernel<PREC, NQ>), dim3(grid), dim3(THREADS), lds, st, d, (const char*)Q,
                      (const char*)K, (const char*)Vt, key_a, key_b, (const char*)table_pair, O, LSE);
   return (int)hipGetLastError();
@@ -250,6 +307,6 @@ extern "C" int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void*
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
-    return launch_fwd<BEVR_PREC_BF16, 4>(*d, Q, K, Vt, key_a, key_b, table_pair, O, LSE, st);
+    return launch_fwd<BEVR_PREC_BF16, 2>(*d, Q, K, Vt, key_a, key_b, table_pair, O, LSE, st);
   return launch_fwd<BEVR_PREC_F32, 2>(*d, Q, K, Vt, key_a, key_b, table_pair, O, LSE, st);
 }

@@ -1,0 +1,124 @@
+// Query-stationary tile machinery shared by the forward and the query-side backward:
+// per 64-key step, the keys' table coordinates, the bounding box of the table taps they need for this
+// workgroup's query tile, and the LDS window holding exactly that part of the rpe table.
+//
+// Why a window: a (query tile) x (key step) block touches the table only inside
+//   rows    [i0 + min floor(a), i0 + 31 + max floor(a) + 1]
+//   columns [floor(j_lo rx + min b), floor(j_hi rx + max b) + 1]
+// When the keys of a step are spatially compact (regular TSA grid; SCA keys ordered along a k-d tree of
+// their static camera projections) that box is a few thousand entries, so the 4-tap bilinear gather of
+// every (query, key) pair is served from LDS -- conflict-free, because the 32 lanes of a tile are 32
+// consecutive table rows of one column -- instead of from L2.  Steps whose box does not fit fall back to
+// gathering from global memory; both paths compute the same thing.
+#pragma once
+#include "bevr_common.h"
+
+constexpr int KT = 64;           // keys per step
+constexpr int THREADS = 256;     // 4 waves
+constexpr int WIN_PITCH = 64;    // window rows (pair entries) per column = one wave-wide load per column
+constexpr int WIN_ROWS_MAX = 63; // 32 + (Amax - Amin) must not exceed this (accumulation window needs +1 row)
+
+// per-key constants in LDS (16 B, read as a broadcast)
+struct KeyW {
+  int aoff;    // global path: byte offset ((A + y_off) + x_off * Hp) * 8 into the head's pair table
+  float fy;    // frac(a)
+  float b;     // clamped column coordinate
+  int arow8;   // window path: (A - Amin) * 8
+};
+
+struct WinInfo {
+  int ok;       // window path valid for this step
+  int xlo;      // first table column in the window (un-padded coordinates)
+  int ncols;
+  int amin;     // min floor(a) over the live keys of the step
+  int nrows;    // 32 + amax - amin
+  float xlo_f;
+  int pad0, pad1;
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = min(v, __shfl_xor(v, s));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = max(v, __shfl_xor(v, s));
+  return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = fminf(v, __shfl_xor(v, s));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+  return v;
+}
+
+// Executed by the 64 lanes of wave 0: lane = key within the step.  Returns this key's constants and fills
+// `wi` (identical in all lanes).
+__device__ __forceinline__ KeyW stage_keys(float a, float b, bool live, const bevr_attn_desc& d, float jrx_lo,
+                                           float jrx_hi, int max_cols, WinInfo& wi) {
+  const float aL = -(float)(d.Sp + 1), aU = (float)(d.Ht + 1);
+  const float half = (float)(d.Wt / 2);
+  const float bL = -(half + 2.0f), bU = (float)(d.Wt + 1);
+  a = fminf(fmaxf(a, aL), aU);
+  b = fminf(fmaxf(b, bL), bU);
+  const float af = floorf(a);
+  const int A = (int)af;
+  const int amin = wave_min_i(live ? A : 0x7fffffff), amax = wave_max_i(live ? A : (int)0x80000000);
+  const float bmin = wave_min_f(live ? b : 3.0e38f), bmax = wave_max_f(live ? b : -3.0e38f);
+  wi.amin = amin;
+  wi.nrows = 32 + amax - amin;
+  wi.xlo = (int)floorf(jrx_lo + bmin) - 1;
+  const int xhi = (int)floorf(jrx_hi + bmax) + 2;
+  wi.ncols = xhi - wi.xlo + 1;
+  wi.xlo_f = (float)wi.xlo;
+  wi.ok = (amax >= amin) && (wi.nrows <= WIN_ROWS_MAX) && (wi.ncols <= max_cols);
+  wi.pad0 = wi.pad1 = 0;
+  KeyW k;
+  k.aoff = ((A + d.y_off) + d.x_off * d.Hp) * 8;
+  k.fy = a - af;
+  k.b = live ? b : bmin;   // dead (padded) keys: any in-window column; their logits are masked anyway
+  k.arow8 = live ? (A - amin) * 8 : 0;
+  return k;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent window ("region"): a fixed-capacity box of the table, WIN_PITCH rows x NCOL columns, anchored
+// at table coordinates (ax0, ay0) relative to this workgroup's first BEV row.  A step whose bounding box
+// lies inside the current region reuses it; otherwise the region is re-anchored (centred on the new box) and
+// refilled.  Consecutive steps of a k-d ordered key list mostly stay inside one region -- in particular the
+// long runs of out-of-image keys that the projector pins to one pixel.
+struct Region {
+  int ax0, ay0;   // un-padded table column of window column 0; floor(a) value of window row 0 (for lane row 0)
+};
+
+__device__ __forceinline__ bool region_contains(const Region& rg, const WinInfo& wi, int ncol_cap) {
+  return wi.xlo >= rg.ax0 && wi.xlo + wi.ncols <= rg.ax0 + ncol_cap && wi.amin >= rg.ay0 &&
+         wi.amin + wi.nrows <= rg.ay0 + WIN_ROWS_MAX;
+}
+
+// Centre the region on the step's box, clamped so that every window entry is inside the padded table.
+__device__ __forceinline__ Region region_anchor(const WinInfo& wi, const bevr_attn_desc& d, int i0, int ncol_cap) {
+  Region rg;
+  int xi = wi.xlo - (ncol_cap - wi.ncols) / 2 + d.x_off;                 // padded column index of window col 0
+  xi = max(0, min(xi, d.Wp - ncol_cap));
+  int yi = i0 + wi.amin - (WIN_ROWS_MAX - wi.nrows) / 2 + d.y_off;       // padded row index of window row 0
+  yi = max(0, min(yi, d.Hp - WIN_PITCH));
+  rg.ax0 = xi - d.x_off;
+  rg.ay0 = yi - d.y_off - i0;
+  return rg;
+}
+
+// Cooperative fill of the whole region: one wave-wide 8-byte load per column (lane = row).
+__device__ __forceinline__ void load_region(char* win, const char* tbl, const bevr_attn_desc& d, const Region& rg,
+                                            int i0, int ncol_cap, int wave, int lane) {
+  const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
+  for (int c = wave; c < ncol_cap; c += THREADS / 64) {
+    f32x2 v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)(rg.ax0 + c + d.x_off) * d.Hp + y0) * 8);
+    *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * 8) = v;
+  }
+}

@@ -8,6 +8,7 @@ device and broadcast over the batch as a view.
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .SCA_deform_attn import SCADeformableAttention
 
 
@@ -62,23 +63,30 @@ class SpatialCrossAttn(nn.Module):
         return self.projector.bev_grid_to_camera(self.sample_3d_points())
 
     def reference_points(self, vehicle_code: int, device) -> torch.Tensor:
-        """(V, S/2, S*D, 2) in (x, y), cached per device."""
+        """((V, S/2, S*D, 2) reference points in (x, y), (V, N) key order), cached per device."""
         key = (int(vehicle_code), str(device))
         if key not in self._ref_cache:
             pts = self.projector.bev_grid_to_camera(self.sample_3d_points(), device=device)[int(vehicle_code)]
             r = torch.stack(pts, 0)                                    # (V, 2, h, w, d)
             V, _, h, w, d = r.shape
-            self._ref_cache[key] = r.permute(0, 2, 3, 4, 1).reshape(V, h, w * d, 2).contiguous()
+            ref = r.permute(0, 2, 3, 4, 1).reshape(V, h, w * d, 2).contiguous()
+            # static k-d ordering of each view's keys by their projected position (ops.kd_key_order)
+            S, D = self.bev_feat_shape, self.bev_depth_dim
+            yx = ref.reshape(V, -1, 2)[..., (1, 0)].double().cpu().numpy()
+            order = torch.stack([torch.from_numpy(ops.kd_key_order(yx[v], S, 2 * S * D - 1)) for v in range(V)], 0)
+            self._ref_cache[key] = (ref, order.to(device))
         return self._ref_cache[key]
 
     def forward(self, query, img_feat, vehicle_type_idx, wandb_log_dict, return_wandb_log=True):
         B = query.shape[0]
         code = int(vehicle_type_idx) if not torch.is_tensor(vehicle_type_idx) else self._code(vehicle_type_idx)
-        ref = self.reference_points(code, query.device)[None].expand(B, -1, -1, -1, -1)
+        ref, order = self.reference_points(code, query.device)
+        ref = ref[None].expand(B, -1, -1, -1, -1)
         if img_feat.dim() == 4:
             img_feat = img_feat.reshape(B, self.num_views, *img_feat.shape[1:])
         return self.spatial_deform_attn(x=img_feat, query=query, reference_points=ref,
-                                        wandb_log_dict=wandb_log_dict, return_wandb_log=return_wandb_log)
+                                        wandb_log_dict=wandb_log_dict, return_wandb_log=return_wandb_log,
+                                        key_order=order)
 
     def _code(self, t: torch.Tensor) -> int:
         # One rig per model in the reference (VEHICLE_TYPE_CODE); avoid its per-call .item() sync when possible.

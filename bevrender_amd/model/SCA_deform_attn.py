@@ -79,8 +79,10 @@ class SCADeformableAttention(nn.Module):
             outs.append(pos.reshape(B, g, Hk * Wk, 2))
         return torch.stack(outs, 1)
 
-    def forward(self, x, query, reference_points, wandb_log_dict, return_wandb_log=True):
-        """x (B, V, C, Hi, Wi); query (B, C, S, S); reference_points (B, V, S/2, S*D, 2) in (x, y)."""
+    def forward(self, x, query, reference_points, wandb_log_dict, return_wandb_log=True, key_order=None):
+        """x (B, V, C, Hi, Wi); query (B, C, S, S); reference_points (B, V, S/2, S*D, 2) in (x, y).
+        key_order (V, N) long, optional: a per-view permutation of the keys (SpatialCrossAttn passes the static
+        k-d order of the camera projections); it changes no result, only the memory locality of the bias."""
         B, V, C, Hi, Wi = x.shape
         S = query.shape[-1]
         if V != self.n_views:
@@ -88,6 +90,8 @@ class SCADeformableAttention(nn.Module):
         g = self.n_groups
         pos = self.key_positions(query, reference_points.to(query.dtype))       # (B, V, g, N, 2)
         N = pos.shape[3]
+        if key_order is not None:
+            pos = pos.gather(3, key_order[None, :, None, :, None].expand(B, V, g, N, 2))
         pos = pos.reshape(B * V * g, N, 2)
         xs = ops.sample_features(x.reshape(B * V, C, Hi, Wi), pos, g)            # (B*V, N, C)
         k = F.linear(xs, self.proj_k.weight.flatten(1), self.proj_k.bias)

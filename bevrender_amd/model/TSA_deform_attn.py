@@ -50,6 +50,16 @@ class TSADeformableAttention(nn.Module):
         self.proj_views = nn.Conv2d(cg * n_views, cg, 1)   # unused, kept for state_dict parity
         self.rpe_table = nn.Parameter(torch.zeros(n_heads, 2 * self.bev_h - 1, 2 * self.bev_w - 1))
         trunc_normal_(self.rpe_table, std=0.01)
+        self._order_cache = {}
+
+    def _key_order(self, Hk, Wk, device):
+        """Static k-d ordering of the regular key grid (compact 64-key steps; see ops.kd_key_order)."""
+        key = (Hk, Wk, str(device))
+        if key not in self._order_cache:
+            ref = normalized_grid(Hk, Wk, torch.float64, "cpu").reshape(-1, 2).numpy()
+            order = ops.kd_key_order(ref, self.bev_h, 2 * self.bev_w - 1)
+            self._order_cache[key] = torch.from_numpy(order).to(device)
+        return self._order_cache[key]
 
     def key_positions(self, query):
         """offset head -> tanh range -> + regular grid: (B*g, Hk*Wk, 2) in (y, x).  reference :158-196."""
@@ -63,7 +73,10 @@ class TSADeformableAttention(nn.Module):
         pos = off.permute(0, 2, 3, 1) + normalized_grid(Hk, Wk, off.dtype, off.device)[None]
         if not self.scale_offset_range:
             pos = pos.clamp(-1.0, 1.0)
-        return pos.reshape(B * g, Hk * Wk, 2)
+        pos = pos.reshape(B * g, Hk * Wk, 2)
+        if Hk > 1 and Wk > 1:
+            pos = pos.index_select(1, self._key_order(Hk, Wk, pos.device))   # order-invariant for the softmax
+        return pos
 
     def forward(self, x, query, wandb_log_dict, return_wandb_log=True):
         if x is None:                       # no history: self-attention on the query (:142-143)

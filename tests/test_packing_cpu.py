@@ -91,3 +91,22 @@ def test_pack_unpack_roundtrip():
     Qp = ops.pack_query(x, h) / (c ** -0.5 * ops.LOG2E)
     back = ops.unpack_out(Qp, S, c)                         # (B, S*S, C) rows i*S + j
     np.testing.assert_allclose(back.numpy(), x.reshape(3, h * c, S * S).permute(0, 2, 1).numpy(), rtol=1e-6)
+
+
+def test_kd_key_order_is_a_permutation_with_compact_leaves():
+    rng = np.random.default_rng(0)
+    S, D = 40, 5
+    Wt = 2 * S * D - 1
+    N = 5000 + 17
+    pos = rng.uniform(-1, 1, size=(N, 2))
+    pos[: N // 3] = -1.0                      # masked keys pinned to the corner, as the projector does
+    order = ops.kd_key_order(pos, S, Wt)
+    assert sorted(order.tolist()) == list(range(N))
+    a = (1 - pos[order, 0]) * (S - 1) / 2
+    b = (1 - pos[order, 1]) * (Wt - 1) / 4
+    area_sorted, area_nat = [], []
+    a0, b0 = (1 - pos[:, 0]) * (S - 1) / 2, (1 - pos[:, 1]) * (Wt - 1) / 4
+    for k in range(0, N - 64, 64):
+        area_sorted.append((np.ptp(a[k:k + 64]) + 1) * (np.ptp(b[k:k + 64]) + 1))
+        area_nat.append((np.ptp(a0[k:k + 64]) + 1) * (np.ptp(b0[k:k + 64]) + 1))
+    assert np.median(area_sorted) * 20 < np.median(area_nat)

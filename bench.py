@@ -77,9 +77,8 @@ class LiftBlock(nn.Module):
             elif isinstance(m, nn.Embedding):
                 nn.init.uniform_(m.weight)
         # parameters the reference constructs but never uses get no gradient: keep them out of the all-reduce
-        for n, p in self.named_parameters():
-            if any(t in n for t in ("proj_q", "proj_views", "down_proj", "ffn_tsa", "ffn_sca")):
-                p.requires_grad_(False)
+        from bevrender_amd.parallel import freeze_unused_parameters
+        freeze_unused_parameters(self, n_views=V)
 
     def encode(self, feats, prev_bev):
         B = feats.shape[0] // self.layers[0].spatial_cross_attn.num_views
@@ -104,14 +103,20 @@ def attn_flops(kind, geom):
     return 2.0 * 32 * pairs * n_mm
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline(seconds_budget=20.0):
     """The oracle (CPU restatement of the reference, materialised formulation) on the host cores:
     the same unit of work (L=2 layers, T=2 frames, V=6 views, fwd+bwd on the last frame) at a BEV side the
     materialised (M x N) tensors fit in host RAM."""
     from oracle import bevrender_oracle as O
     S, C, h, D, V, L = 28, 64, 2, 5, 6, 2
     torch.manual_seed(15213)
-    cores = os.cpu_count() or 1
+    # the threads this process may actually use: a GPU box hands one GPU's job a 16-core share of a much
+    # larger host, and os.cpu_count() would oversubscribe it by an order of magnitude
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = int(os.environ.get("BEVR_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
 
     def mk_params():
@@ -159,12 +164,16 @@ def cpu_baseline(seconds_budget=25.0):
         out = run(q0, feats[1], prev)
         out.square().mean().backward()
 
+    t_w = time.perf_counter()
     one_sample()  # warm-up (allocator, thread pool)
+    print(f"[bench] cpu_baseline warm-up sample: {time.perf_counter() - t_w:.1f} s on {cores} threads",
+          file=sys.stderr, flush=True)
     n, t0 = 0, time.perf_counter()
     while True:
         one_sample()
         n += 1
         dt = time.perf_counter() - t0
+        print(f"[bench] cpu_baseline: {n} samples, {dt:.1f} s", file=sys.stderr, flush=True)
         if dt > seconds_budget or n >= 50:
             break
     return {"value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
@@ -184,14 +193,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    from bevrender_amd import parallel
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
+    rank, world, local_rank = parallel.init_distributed("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
     dev = torch.device("cuda", local_rank)
 
     from bevrender_amd import _lib, ops
@@ -200,11 +206,8 @@ def main():
     Hi, Wi = img_h // 4, img_w // 4
     torch.manual_seed(15213 + rank)
     model = LiftBlock(S, C, heads, D, V, L, img_w, img_h, args.precision, dev).to(dev)
-    if world > 1:
-        # identical initial weights on every rank (DDP broadcasts rank 0's); one flat 25 MB bucket holds all grads
-        net = nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)
-    else:
-        net = model
+    # identical initial weights on every rank (DDP broadcasts rank 0's); one flat 25 MB bucket holds all grads
+    net = parallel.wrap_data_parallel(model, local_rank)
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
 
     gen = torch.Generator(device=dev).manual_seed(15213 + rank)

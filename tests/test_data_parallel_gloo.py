@@ -1,0 +1,94 @@
+"""N>1 path on CPU: two gloo ranks, each with half the batch, must produce the gradients of one process
+on the whole batch (mean-reduced loss), with the never-used parameters frozen instead of searched for."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from bevrender_amd import parallel
+from bevrender_amd.model.model_utils import LayerNormProxy, TransformerMLPWithConv
+
+
+class TinyGlue(nn.Module):
+    """Encoder-layer glue without the GPU-only attention ops (those are per-sample independent, so the
+    data-parallel contract is the same): LPU conv + shared LN + MLP, plus reference-style dead parameters."""
+
+    def __init__(self, C=8):
+        super().__init__()
+        self.layer_norm = LayerNormProxy(C)
+        self.lpu = nn.Conv2d(C, C, 3, 1, 1, groups=C)
+        self.mlp = TransformerMLPWithConv(C, 2, 0.0)
+        self.proj_q = nn.Conv2d(C, C, 1)          # never used, as in the reference
+        self.ffn_tsa = nn.Linear(4, 4)            # never used
+
+    def forward(self, x):
+        x = x + self.lpu(x)
+        x = self.mlp(self.layer_norm(x)) + x
+        return x.square().mean()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, state, x, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, _ = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    model = TinyGlue()
+    model.load_state_dict(state)
+    frozen = parallel.freeze_unused_parameters(model)
+    assert any("proj_q" in n for n in frozen) and any("ffn_tsa" in n for n in frozen)
+    net = parallel.wrap_data_parallel(model)
+    loss = net(parallel.shard_batch(x, rank, world))
+    loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
+    if rank == 0:
+        out_q.put({k: v.numpy() for k, v in grads.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_single_process():
+    torch.manual_seed(0)
+    ref = TinyGlue()
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    x = torch.randn(4, 8, 6, 6)
+    parallel.freeze_unused_parameters(ref)
+    ref(x).backward()
+    want = {n: p.grad.numpy() for n, p in ref.named_parameters() if p.requires_grad}
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, state, x, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert set(got) == set(want)
+    for k in want:
+        # mean over the full batch == average of the two half-batch means
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_shard_batch_and_world1_passthrough():
+    t = torch.arange(8).reshape(8, 1)
+    assert parallel.shard_batch(t, 1, 4).flatten().tolist() == [2, 3]
+    with pytest.raises(ValueError):
+        parallel.shard_batch(t, 0, 3)
+    m = TinyGlue()
+    assert parallel.wrap_data_parallel(m) is m

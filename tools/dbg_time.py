@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bevrender_amd import ops, _lib
 torch.manual_seed(0)
 B,V,C,h,S,D=1,2,64,2,200,5

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(THREADS, PREC == BEVR_PREC_BF16 ? 2 : 1) void attn_
     const bool use_win = wi.ok != 0;   // workgroup-uniform
     if (use_win && !region_contains(rg, wi, WIN_COLS)) {
       rg = region_anchor(wi, d, i0, WIN_COLS);
-      load_region(win, tbl, d, rg, i0, WIN_COLS, wave, lane);
+      load_region(win, tbl, d, rg, i0, WIN_COLS, THREADS / 64, wave, lane);
       __syncthreads();
     }
     const float ax0_f = (float)rg.ax0;

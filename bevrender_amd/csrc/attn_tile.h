@@ -115,9 +115,9 @@ __device__ __forceinline__ Region region_anchor(const WinInfo& wi, const bevr_at
 
 // Cooperative fill of the whole region: one wave-wide 8-byte load per column (lane = row).
 __device__ __forceinline__ void load_region(char* win, const char* tbl, const bevr_attn_desc& d, const Region& rg,
-                                            int i0, int ncol_cap, int wave, int lane) {
+                                            int i0, int ncol_cap, int n_wave, int wave, int lane) {
   const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
-  for (int c = wave; c < ncol_cap; c += THREADS / 64) {
+  for (int c = wave; c < ncol_cap; c += n_wave) {
     f32x2 v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)(rg.ax0 + c + d.x_off) * d.Hp + y0) * 8);
     *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * 8) = v;
   }

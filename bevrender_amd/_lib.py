@@ -75,7 +75,7 @@ def lib() -> C.CDLL:
         L.bevr_strerror.argtypes = [C.c_int]
         L.bevr_attn_table_dims.argtypes = [dp]
         L.bevr_attn_fwd.argtypes = [dp, vp, vp, vp, fp, fp, fp, fp, fp, vp]
-        L.bevr_attn_bwd_q.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, fp, fp, fp, fp, vp]
+        L.bevr_attn_bwd_q.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, fp, fp, fp, fp, fp, vp]
         L.bevr_attn_bwd_k.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, vp, fp, fp] + [fp] * 4 + [vp]
         L.bevr_sample_fwd.argtypes = [fp, fp, fp] + [ip] * 5 + [vp]
         L.bevr_sample_bwd.argtypes = [fp] * 5 + [ip] * 5 + [vp]

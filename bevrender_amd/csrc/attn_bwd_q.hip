@@ -5,59 +5,68 @@
 //     (preloaded into the accumulators of the two MFMA chains),
 //   * dQ^T[c][q] += K^T[c][key] dS^T[key][q] takes dS^T straight from the accumulator (B operand),
 //   * the table gradient of a (query tile x key step) block lands inside the same box the bias was read
-//     from: each wave accumulates it in a private LDS window (plain read-modify-write; 32 lanes = 32
-//     consecutive rows: conflict-free) that is flushed to HBM with contiguous float atomics only when the
-//     region moves.  Steps whose box does not fit scatter straight to global memory.
-// Workgroup = 8 waves (2 per SIMD: the read-modify-write chains are LDS-latency bound) on one 32-row x
-// 8-column query tile: wave w owns column pair (w & 3) and the key half (w >> 2) of every 64-key step; the two
-// key halves' dQ partial sums are merged through LDS at the end.
+//     from: it is accumulated in ONE workgroup-shared LDS window of the region's shape with 64-bit
+//     fixed-point integer atomics (ds_add_u64) and flushed to HBM with contiguous float atomics only when
+//     the region moves.  Measured on gfx950: LDS float atomics cost ~160 cycles per wave instruction and a
+//     plain read-modify-write needs per-wave windows, lane regrouping and ordering that pushed the kernel
+//     into scratch spills; the integer adds are cheap, order-free and make the window sums bit-reproducible.
+//     The fixed-point unit is 2^-52 of a bound on |dS| handed in by the caller (grad_scale).
+//     Steps whose box does not fit scatter straight to global memory with float atomics.
+// Workgroup = 16 waves (4 per SIMD, <= 128 registers each) on one 32-row x 8-column query tile: wave w owns
+// column (w & 7) and the key half (w >> 3) of every 64-key step; the two key halves' dQ partial sums are merged
+// through LDS at the end.
 // Recomputes S from Q, K and the bias instead of storing any (M x N) tensor.
 // Gradient semantics: see include/bevrender_hip.h (log2-domain inputs as handed in).
 #include "attn_tile.h"
 
 namespace {
 
-constexpr int TQ = 512;   // threads per workgroup
+constexpr int TQ = 1024;  // threads per workgroup
 constexpr int NWAVE = TQ / 64;
-constexpr int NQ = 2;     // query columns per wave
+constexpr int NCOL = 8;   // query columns per workgroup (one per wave of a key half)
 
 template <int PREC> struct LdsQ {
   static constexpr int EB = Elem<PREC>::bytes;
-  // region capacity (columns of the shared table window) and per-wave accumulation-window width
-  static constexpr int CAP_MAX = PREC == BEVR_PREC_BF16 ? 64 : 48;
-  static constexpr int WACC = PREC == BEVR_PREC_BF16 ? 40 : 32;
+  static constexpr int CAP = PREC == BEVR_PREC_BF16 ? 64 : 48;   // region capacity (table columns)
   static constexpr int R_STRIDE = 32 * EB + 16;   // row-layout tiles (K, V): bytes per key row
   static constexpr int T_STRIDE = KT * EB + 16;   // transposed tile (Kt): bytes per channel row
   static constexpr int R_BYTES = KT * R_STRIDE;
   static constexpr int T_BYTES = 32 * T_STRIDE;
   static constexpr int C_BYTES = KT * 16 + 32;
   static constexpr int BUF = 2 * R_BYTES + T_BYTES + C_BYTES;
-  static constexpr int WIN = CAP_MAX * WIN_PITCH * 8;
-  static constexpr int ACC1 = (WACC + 3) * WIN_PITCH * 4;   // one wave's window (floats, WIN_PITCH rows per column) + dummy columns (a dummy update touches [off, off + AP + 1])
-  static constexpr int TOTAL = 2 * BUF + WIN + NWAVE * ACC1;
+  static constexpr int WIN = CAP * WIN_PITCH * 8;
+  static constexpr int CELLS = CAP * WIN_PITCH;   // accumulation window: one 64-bit cell per table entry
+  static constexpr int TOTAL = 2 * BUF + WIN + CELLS * 8;
 };
+
+// x (already multiplied by the fixed-point scale, |x| < 2^62) -> two's-complement 64-bit integer, floor rounding.
+// Exact for the float's 24 significant bits: hi = floor(x 2^-32) (exact), lo = x - hi 2^32 in [0, 2^32).
+__device__ __forceinline__ unsigned long long to_fixed64(float x) {
+  const float xh = floorf(x * 2.3283064365386963e-10f);
+  const float xl = fmaf(xh, -4294967296.0f, x);
+  const unsigned lo = (unsigned)xl;          // v_cvt_u32_f32 saturates at 2^32 - 1
+  const unsigned hi = (unsigned)(int)xh;
+  return ((unsigned long long)hi << 32) | lo;
+}
 
 template <int PREC>
 __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Kt,
     const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const float* __restrict__ LSE,
-    const float* __restrict__ delta, float* __restrict__ dQ, float* __restrict__ dtable) {
+    const float* __restrict__ delta, const float* __restrict__ grad_scale, float* __restrict__ dQ,
+    float* __restrict__ dtable) {
   typedef LdsQ<PREC> L;
   constexpr int EB = L::EB;
-  constexpr int WACC = L::WACC;
-  constexpr int AP = WIN_PITCH;   // accumulation-window row pitch (floats)
+  constexpr int CAP = L::CAP;
   static_assert(L::TOTAL <= 160 * 1024, "LDS budget");
-  // Three separate LDS objects, not one carved buffer: the compiler then knows that the read-modify-write
-  // stores into the accumulation windows cannot alias the staged tiles, key constants or table window, and
-  // keeps hoisting those loads across them (with one buffer every load waited behind the previous key's
-  // stores and the loop ran at LDS latency: ~900 cycles per 64 pairs).
+  // separate LDS objects: loads of the staged tiles / table window may be scheduled across the window atomics
   __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
   __shared__ __attribute__((aligned(16))) char win[L::WIN];
-  __shared__ __attribute__((aligned(16))) float acc_all[NWAVE * (WACC + 3) * AP];
+  __shared__ __attribute__((aligned(16))) unsigned long long accw[L::CELLS];
 
   const int n_rb = d.Sp / 32;
-  const int n_cb = (d.S + 4 * NQ - 1) / (4 * NQ);
+  const int n_cb = (d.S + NCOL - 1) / NCOL;
   const int n_tile = n_rb * n_cb;
   const int n_ph = d.n_prob * d.heads;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -70,8 +79,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   const int qb = prob / d.q_div;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
-  const int cp = wave & 3, kh = wave >> 2;
-  float* acc = acc_all + wave * ((WACC + 3) * AP);
+  const int col = wave & (NCOL - 1), kh = wave / NCOL;
   const int Mp = d.S * d.Sp;
   const int i0 = rb * 32;
 
@@ -87,56 +95,39 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   const int Hp8 = d.Hp * 8;
   const int Hq = d.Hp + 1;
   const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
-  const int j_first = cb * 4 * NQ;
-  const int j_last = min(j_first + 4 * NQ - 1, d.S - 1);
+  const int j_first = cb * NCOL;
+  const int j_last = min(j_first + NCOL - 1, d.S - 1);
   const float jrx_lo = (float)j_first * rx, jrx_hi = (float)j_last * rx;
-  // A wave's two columns must never share table cells (their updates go out in one LDS instruction): adjacent
-  // columns when rx >= 2 (SCA: tx advances ~5 cells per column), columns 4 apart otherwise (TSA: rx = 1).
-  const bool rx2 = rx >= 2.0f;
-  const int dj = rx2 ? 1 : 4;
-  // Region capacity: chosen so that a step box inside the region implies every wave's two columns stay inside
-  // its WACC-wide accumulation window: the wave spans dj of the block's columns, the region all of them.
-  const int cap = min(L::CAP_MAX, WACC - 4 + (int)floorf((float)(j_last - j_first - dj) * rx));
+  const float gscale = grad_scale[0], ginv = grad_scale[1];
 
-  Frag<PREC> qf[NQ], dof[NQ];
-  float jrx[NQ], lse[NQ], dlt[NQ];
-  int jcol[NQ];
-  bool live[NQ];
+  // this wave's query column
+  const int jcol = j_first + col;
+  const bool live = jcol < d.S;
+  const int jc = live ? jcol : d.S - 1;   // columns past the grid: a clamped copy that contributes nothing
+  const float jrx = (float)jc * rx;
+  const size_t mq = (size_t)jc * d.Sp + i0 + lq;
+  Frag<PREC> qf, dof;
+  qf.load(Qh + mq * 32 * EB, hi);
+  dof.load(dOh + mq * 32 * EB, hi);
+  const float lse = LSE[(size_t)ph * Mp + mq];
+  float dlt = delta[(size_t)ph * Mp + mq];
+  if (!live) {
+    if constexpr (PREC == BEVR_PREC_BF16) {
+      dof.v[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      dof.v[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    } else {
 #pragma unroll
-  for (int t = 0; t < NQ; ++t) {
-    int j = j_first + (rx2 ? cp * NQ + t : cp + 4 * t);
-    jcol[t] = j;
-    live[t] = j < d.S;
-    int jc = live[t] ? j : d.S - 1;
-    jrx[t] = (float)jc * rx;
-    size_t mq = (size_t)jc * d.Sp + i0 + lq;
-    qf[t].load(Qh + mq * 32 * EB, hi);
-    dof[t].load(dOh + mq * 32 * EB, hi);
-    lse[t] = LSE[(size_t)ph * Mp + mq];
-    dlt[t] = delta[(size_t)ph * Mp + mq];
-    if (!live[t]) {  // duplicate of column S-1: must contribute nothing
-      if constexpr (PREC == BEVR_PREC_BF16) {
-        dof[t].v[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        dof[t].v[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      } else {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) dof[t].v[k] = 0.f;
-      }
-      dlt[t] = 0.f;
+      for (int k = 0; k < 16; ++k) dof.v[k] = 0.f;
     }
+    dlt = 0.f;
   }
-  // first window column of this wave, relative to the region's column 0 (lower bound of floor(tx) - ax0)
-  const int wcol0 = max(0, (int)floorf(jrx[0] - jrx_lo) - 1);
   const int ilane = i0 + lq;
   const int rowoff = ilane * 8;
   const int xoffHp = d.x_off * d.Hp;
-  const int dummy_off = WACC * AP + lane;   // per-lane cell of the dummy column: target of non-live columns
 
-  f32x16 dq[NQ];
+  f32x16 dq;
 #pragma unroll
-  for (int t = 0; t < NQ; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dq[t][r] = 0.f;
+  for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 
   constexpr int RCH_ROW = 32 * EB / 16;
   constexpr int TCH_ROW = KT * EB / 16;
@@ -165,7 +156,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     }
     if (tid < KT) {   // exactly wave 0
       WinInfo wi;
-      KeyW kw = stage_keys(st_a, st_b, step * KT + tid < d.N, d, jrx_lo, jrx_hi, cap, wi);
+      KeyW kw = stage_keys(st_a, st_b, step * KT + tid < d.N, d, jrx_lo, jrx_hi, CAP, wi);
       *reinterpret_cast<KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES + tid * 16) = kw;
       if (tid == 0) *reinterpret_cast<WinInfo*>(base + 2 * L::R_BYTES + L::T_BYTES + KT * 16) = wi;
     }
@@ -178,14 +169,19 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   Region rg;
   rg.ax0 = -(1 << 28);
   rg.ay0 = 0;
-  bool acc_live = false;   // the accumulation windows hold un-flushed gradient
+  bool acc_live = false;   // the accumulation window holds un-flushed gradient
 
-  // flush this wave's window of region `r`: per column one contiguous run of 64 floats, non-zeros only
-  auto flush = [&](const Region& r) {
-    const size_t y0 = (size_t)(i0 + r.ay0 + d.y_off) + lane;
-    for (int c = 0; c < WACC; ++c) {
-      float v = acc[c * AP + lane];
-      if (v != 0.f) atomicAdd(dtb + (size_t)(r.ax0 + wcol0 + c + d.x_off) * Hq + y0, v);
+  // drain the shared window of region `r` (all threads): fixed point -> float, non-zero cells only, then clear.
+  // A column of the window is 64 consecutive rows of one table column: 256-byte contiguous atomics.
+  auto flush_and_clear = [&](const Region& r, bool do_flush) {
+    for (int cell = tid; cell < L::CELLS; cell += TQ) {
+      const unsigned long long v = accw[cell];
+      accw[cell] = 0ull;
+      if (do_flush && v != 0ull) {
+        const int c = cell / WIN_PITCH, row = cell % WIN_PITCH;
+        const float f = ((float)(int)(unsigned)(v >> 32) * 4294967296.0f + (float)(unsigned)v) * ginv;
+        atomicAdd(dtb + (size_t)(r.ax0 + c + d.x_off) * Hq + (size_t)(i0 + r.ay0 + d.y_off + row), f);
+      }
     }
   };
 
@@ -195,12 +191,11 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     if (step + 1 < n_step) stage_load(step + 1);
     const WinInfo wi = *reinterpret_cast<const WinInfo*>(base + 2 * L::R_BYTES + L::T_BYTES + KT * 16);
     const bool use_win = wi.ok != 0;   // workgroup-uniform
-    if (use_win && !region_contains(rg, wi, cap)) {
+    if (use_win && !region_contains(rg, wi, CAP)) {
       // every wave finished the previous step (barrier at the end of the loop body): safe to drain and move
-      if (acc_live) flush(rg);
-      rg = region_anchor(wi, d, i0, cap);
-      load_region(win, tbl, d, rg, i0, cap, NWAVE, wave, lane);
-      for (int c = 0; c < WACC; ++c) acc[c * AP + lane] = 0.f;
+      flush_and_clear(rg, acc_live);
+      rg = region_anchor(wi, d, i0, CAP);
+      load_region(win, tbl, d, rg, i0, CAP, NWAVE, wave, lane);
       acc_live = true;
       __syncthreads();
     }
@@ -215,153 +210,100 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       const KeyW* kc = reinterpret_cast<const KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES) + kh * 32;
       const bool last = (step == n_step - 1) && d.N < d.Np;
 
-      f32x16 s[NQ], dp[NQ];
+      f32x16 s, dp;
 #pragma unroll
-      for (int t = 0; t < NQ; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[t][r] = -lse[t]; dp[t][r] = -dlt[t]; }
-        s[t] = mma_frag(kf, qf[t], s[t]);       // S^T - LSE
-        dp[t] = mma_frag(vkf, dof[t], dp[t]);   // dP^T - delta
-      }
+      for (int r = 0; r < 16; ++r) { s[r] = -lse; dp[r] = -dlt; }
+      s = mma_frag(kf, qf, s);       // S^T - LSE
+      dp = mma_frag(vkf, dof, dp);   // dP^T - delta
 
       if (use_win) {
-        // One basic block per key pair (no branches), so the scheduler overlaps the next keys' LDS reads with
-        // this key's arithmetic.  Table-gradient accumulation, per accumulator register r (key A = crow(r,0) in
-        // lanes 0-31, key B = crow(r,1) in lanes 32-63, for both of the wave's columns t):
-        //   v_permlane32_swap regroups (t0: A|B, t1: A|B) into (A: t0|t1, B: t0|t1); then four plain
-        //   read-modify-writes of this wave's private window, all 64 lanes active each:
-        //     A own rows, A rows + 1, B own rows, B rows + 1.
-        //   Inside one of them the 32 lanes of a half are 32 distinct rows and the two halves are the wave's two
-        //   columns, which never share cells; A and B (which may: the projector pins every out-of-image key to
-        //   one pixel) and the row / row + 1 taps are separated by program order -- a wave's LDS operations
-        //   execute in order.  (LDS float atomics measured ~3.5x slower than this.)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const KeyW c = kc[crow(r, hi)];
           const float wy0 = 1.0f - c.fy;
-          const float bl = c.b - ax0_f;
+          float tx = jrx + (c.b - ax0_f);
+          float xf = floorf(tx);
+          float fx = tx - xf;
+          const int xi = (int)xf;
           const int row = (c.arow8 >> 3) + drow;
-          const bool dead = last && step * KT + kh * 32 + crow(r, hi) >= d.N;
-          int off[NQ];
-          float c00[NQ], c01[NQ], c10[NQ], c11[NQ];
-#pragma unroll
-          for (int t = 0; t < NQ; ++t) {
-            float tx = jrx[t] + bl;
-            float xf = floorf(tx);
-            float fx = tx - xf;
-            const int xi = (int)xf;
-            const char* p = win + xi * (WIN_PITCH * 8) + row * 8;
-            f32x2 t0 = *reinterpret_cast<const f32x2*>(p);
-            f32x2 t1 = *reinterpret_cast<const f32x2*>(p + WIN_PITCH * 8);
-            float u0 = t0[0] * wy0 + t0[1] * c.fy;
-            float u1 = t1[0] * wy0 + t1[1] * c.fy;
-            float sv = s[t][r] + u0 + fx * (u1 - u0);
-            if (dead) sv = BEVR_NEG_BIG;
-            float ds = BEVR_LN2 * fast_exp2(sv) * dp[t][r];
-            s[t][r] = ds;
-            const float w0 = ds * (1.0f - fx), w1 = ds * fx;
-            c00[t] = w0 * wy0; c01[t] = w0 * c.fy; c10[t] = w1 * wy0; c11[t] = w1 * c.fy;
-            // window column of this wave; the clamp is a guard that by construction never binds
-            const int xw = max(0, min(xi - wcol0, WACC - 2));
-            off[t] = live[t] ? xw * AP + row : dummy_off;
-          }
-          // regroup by key: x[0] <- key A (t0 | t1), x[1] <- key B (t0 | t1)
-          // v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second.  Written as inline
-          // asm: with the builtin, hipcc (ROCm 7.2) treated the two results as equal after unrolling and applied
-          // key A's update twice.  "s_nop 1" covers the VALU-write -> permlane-read hazard (2 wait states).
-          auto swap32 = [](auto& a, auto& b) {
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-          };
-          swap32(off[0], off[1]);
-          swap32(c00[0], c00[1]);
-          swap32(c01[0], c01[1]);
-          swap32(c10[0], c10[1]);
-          swap32(c11[0], c11[1]);
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {   // k = 0: key A, k = 1: key B
-            float* g = acc + off[k];
-            float v0 = g[0], v1 = g[AP];
-            g[0] = v0 + c00[k];
-            g[AP] = v1 + c10[k];
-            // rows + 1: lane i's cell here is lane i+1's cell above, so these accesses must stay behind the
-            // stores above in program order.  Laundering the offset through an empty asm makes the compiler
-            // treat it as possibly aliasing (it would otherwise prove g + 1 != g for this thread and reorder)
-            // without fencing the loads of the other LDS objects.
-            int ou = off[k] + 1;
-            asm volatile("" : "+v"(ou));
-            float* gu = acc + ou;
-            float y0 = gu[0], y1 = gu[AP];
-            gu[0] = y0 + c01[k];
-            gu[AP] = y1 + c11[k];
-          }
+          const int cell = xi * WIN_PITCH + row;
+          const char* p = win + cell * 8;
+          f32x2 t0 = *reinterpret_cast<const f32x2*>(p);
+          f32x2 t1 = *reinterpret_cast<const f32x2*>(p + WIN_PITCH * 8);
+          float u0 = t0[0] * wy0 + t0[1] * c.fy;
+          float u1 = t1[0] * wy0 + t1[1] * c.fy;
+          float sv = s[r] + u0 + fx * (u1 - u0);
+          if (last && step * KT + kh * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
+          float ds = BEVR_LN2 * fast_exp2(sv) * dp[r];
+          s[r] = ds;
+          // table gradient: four fixed-point adds into the shared window (order-free, so no per-wave windows)
+          const float dss = ds * gscale;
+          const float w0 = dss * (1.0f - fx), w1 = dss * fx;
+          unsigned long long* g = accw + cell;
+          atomicAdd(g, to_fixed64(w0 * wy0));
+          atomicAdd(g + 1, to_fixed64(w0 * c.fy));
+          atomicAdd(g + WIN_PITCH, to_fixed64(w1 * wy0));
+          atomicAdd(g + WIN_PITCH + 1, to_fixed64(w1 * c.fy));
         }
       } else {
 #pragma unroll
-        for (int t = 0; t < NQ; ++t) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const KeyW c = kc[crow(r, hi)];
-            const float wy0 = 1.0f - c.fy;
-            float tx = jrx[t] + c.b;
-            float xf = floorf(tx);
-            float fx = tx - xf;
-            int xi = (int)xf;
-            unsigned off = (unsigned)(xi * Hp8 + c.aoff + rowoff);
-            f32x2 t0 = *reinterpret_cast<const f32x2*>(tbl + off);
-            f32x2 t1 = *reinterpret_cast<const f32x2*>(tbl + off + Hp8);
-            float u0 = t0[0] * wy0 + t0[1] * c.fy;
-            float u1 = t1[0] * wy0 + t1[1] * c.fy;
-            float sv = s[t][r] + u0 + fx * (u1 - u0);
-            if (last && step * KT + kh * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
-            float ds = BEVR_LN2 * fast_exp2(sv) * dp[t][r];
-            s[t][r] = ds;
-            if (ds != 0.f) {
-              // plain transposed table, row pitch Hp + 1
-              int yi = (c.aoff >> 3) - xoffHp + ilane;
-              float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
-              float w0 = ds * (1.0f - fx), w1 = ds * fx;
-              atomicAdd(g0, w0 * wy0);
-              atomicAdd(g0 + 1, w0 * c.fy);
-              atomicAdd(g0 + Hq, w1 * wy0);
-              atomicAdd(g0 + Hq + 1, w1 * c.fy);
-            }
+        for (int r = 0; r < 16; ++r) {
+          const KeyW c = kc[crow(r, hi)];
+          const float wy0 = 1.0f - c.fy;
+          float tx = jrx + c.b;
+          float xf = floorf(tx);
+          float fx = tx - xf;
+          int xi = (int)xf;
+          unsigned off = (unsigned)(xi * Hp8 + c.aoff + rowoff);
+          f32x2 t0 = *reinterpret_cast<const f32x2*>(tbl + off);
+          f32x2 t1 = *reinterpret_cast<const f32x2*>(tbl + off + Hp8);
+          float u0 = t0[0] * wy0 + t0[1] * c.fy;
+          float u1 = t1[0] * wy0 + t1[1] * c.fy;
+          float sv = s[r] + u0 + fx * (u1 - u0);
+          if (last && step * KT + kh * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
+          float ds = BEVR_LN2 * fast_exp2(sv) * dp[r];
+          s[r] = ds;
+          if (ds != 0.f) {
+            // plain transposed table, row pitch Hp + 1
+            int yi = (c.aoff >> 3) - xoffHp + ilane;
+            float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
+            float w0 = ds * (1.0f - fx), w1 = ds * fx;
+            atomicAdd(g0, w0 * wy0);
+            atomicAdd(g0 + 1, w0 * c.fy);
+            atomicAdd(g0 + Hq, w1 * wy0);
+            atomicAdd(g0 + Hq + 1, w1 * c.fy);
           }
         }
       }
-#pragma unroll
-      for (int t = 0; t < NQ; ++t) dq[t] = mma_acc_b(ktf, s[t], dq[t]);
+      dq = mma_acc_b(ktf, s, dq);
     }
 
     if (step + 1 < n_step) stage_store(buf ^ 1, step + 1);
     __syncthreads();
   }
-  if (acc_live) flush(rg);
+  flush_and_clear(rg, acc_live);
 
-  // ---- merge the two key halves' dQ partial sums (waves w and w + 4) through LDS, then store ------------
-  float* xch = acc_all;   // the accumulation windows are flushed and dead now: 4 waves x 2 x 16 x 64 floats = 32 KiB
-  static_assert(NWAVE * (WACC + 3) * AP * 4 >= 4 * NQ * 16 * 64 * 4, "exchange area");
-  __syncthreads();   // nobody reads the staging buffers or the table window any more
+  // ---- merge the two key halves' dQ partial sums (waves w and w + 8) through LDS, then store ------------
+  // the exchange needs 8 waves x 16 x 64 floats = 32 KiB: split over the (dead) staging area and table window
+  __syncthreads();
+  auto xptr = [&](int c, int r) -> float* {
+    float* basep = c < 4 ? reinterpret_cast<float*>(smem) : reinterpret_cast<float*>(win);
+    return basep + (((c & 3) * 16 + r) * 64 + lane);
+  };
+  static_assert(2 * L::BUF >= 4 * 16 * 64 * 4 && L::WIN >= 4 * 16 * 64 * 4, "exchange halves");
   if (kh == 1) {
 #pragma unroll
-    for (int t = 0; t < NQ; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xch[((cp * NQ + t) * 16 + r) * 64 + lane] = dq[t][r];
+    for (int r = 0; r < 16; ++r) *xptr(col, r) = dq[r];
   }
   __syncthreads();
-  if (kh == 0) {
-    float* dQh = dQ + ((size_t)ph * Mp) * 32;
+  if (kh == 0 && live) {
+    float* row = dQ + ((size_t)ph * Mp + (size_t)jcol * d.Sp + i0 + lq) * 32;
 #pragma unroll
-    for (int t = 0; t < NQ; ++t) {
-      if (!live[t]) continue;
-      size_t mq = (size_t)jcol[t] * d.Sp + i0 + lq;
-      float* row = dQh + mq * 32;
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 v;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = dq[t][4 * g4 + k] + xch[((cp * NQ + t) * 16 + 4 * g4 + k) * 64 + lane];
-        *reinterpret_cast<f32x4*>(row + 8 * g4 + 4 * hi) = v;
-      }
+      for (int k = 0; k < 4; ++k) v[k] = dq[4 * g4 + k] + *xptr(col, 4 * g4 + k);
+      *reinterpret_cast<f32x4*>(row + 8 * g4 + 4 * hi) = v;
     }
   }
 }
@@ -369,13 +311,13 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
 template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt, const void* V, const float* key_a,
            const float* key_b, const float* table_pair, const void* dO, const float* LSE, const float* delta,
-           float* dQ, float* dtable, hipStream_t st) {
-  const int n_rb = d.Sp / 32, n_cb = (d.S + 4 * NQ - 1) / (4 * NQ);
+           const float* grad_scale, float* dQ, float* dtable, hipStream_t st) {
+  const int n_rb = d.Sp / 32, n_cb = (d.S + NCOL - 1) / NCOL;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_rb * n_cb;
   hipLaunchKernelGGL((attn_bwd_q_kernel<PREC>), dim3(grid), dim3(TQ), 0, st, d, (const char*)Q, (const char*)K,
                      (const char*)Kt, (const char*)V, key_a, key_b, (const char*)table_pair, (const char*)dO, LSE,
-                     delta, dQ, dtable);
+                     delta, grad_scale, dQ, dtable);
   return (int)hipGetLastError();
 }
 
@@ -383,16 +325,19 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt
 
 extern "C" int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
                                const float* key_a, const float* key_b, const float* table_pair, const void* dO,
-                               const float* LSE, const float* delta, float* dQ, float* dtable, void* stream) {
+                               const float* LSE, const float* delta, const float* grad_scale, float* dQ,
+                               float* dtable, void* stream) {
   int rc = bevr_check_desc(d);
   if (rc) return rc;
-  if (!Q || !K || !Kt || !V || !key_a || !key_b || !table_pair || !dO || !LSE || !delta || !dQ || !dtable)
+  if (!Q || !K || !Kt || !V || !key_a || !key_b || !table_pair || !dO || !LSE || !delta || !grad_scale || !dQ ||
+      !dtable)
     return BEVR_E_NULL;
   if (!bevr_aligned16(Q) || !bevr_aligned16(K) || !bevr_aligned16(Kt) || !bevr_aligned16(V) || !bevr_aligned16(dO) ||
       !bevr_aligned16(dQ) || !bevr_aligned16(table_pair))
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
-    return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_a, key_b, table_pair, dO, LSE, delta, dQ, dtable, st);
-  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_a, key_b, table_pair, dO, LSE, delta, dQ, dtable, st);
+    return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_a, key_b, table_pair, dO, LSE, delta, grad_scale, dQ, dtable,
+                                  st);
+  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_a, key_b, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
 }

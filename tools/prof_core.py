@@ -12,7 +12,7 @@ v = torch.randn(B * V, N, C, device=dev, requires_grad=True)
 pos = torch.full((B * V, N, 2), -1.0, device=dev)
 n_in = int(N * 0.35)
 base = (torch.rand(B * V, n_in // 64 + 1, 1, 2, device=dev) * 2 - 1).expand(-1, -1, 64, -1).reshape(B * V, -1, 2)[:, :n_in]
-pos[:, :n_in] = base + torch.randn(B * V, n_in, 2, device=dev) * 0.02
+pos[:, :n_in] = base + torch.randn(B * V, n_in, 2, device=dev) * torch.tensor([0.02, 0.003], device=dev)
 pos = (pos + torch.randn_like(pos) * 0.005).requires_grad_(True)
 table = (torch.randn(h, 2 * S - 1, 2 * S * D - 1, device=dev) * 0.1).requires_grad_(True)
 for it in range(int(os.environ.get("ITERS", "2"))):

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops, resolve_precision
-from .model_utils import LayerNormProxy, normalized_grid, trunc_normal_
+from .model_utils import LayerNormProxy, depthwise_conv2d, normalized_grid, trunc_normal_
 
 
 class TSADeformableAttention(nn.Module):
@@ -65,7 +65,9 @@ class TSADeformableAttention(nn.Module):
         """offset head -> tanh range -> + regular grid: (B*g, Hk*Wk, 2) in (y, x).  reference :158-196."""
         B, C, H, W = query.shape
         g = self.n_groups
-        off = self.conv_offset(query.reshape(B * g, C // g, H, W))
+        qg = query.reshape(B * g, C // g, H, W)
+        co = self.conv_offset
+        off = co[3](co[2](co[1](depthwise_conv2d(qg, co[0]))))
         Hk, Wk = off.shape[-2:]
         if self.scale_offset_range:
             rng = off.new_tensor([1.0 / (Hk - 1.0), 1.0 / (Wk - 1.0)]).reshape(1, 2, 1, 1)

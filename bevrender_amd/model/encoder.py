@@ -17,7 +17,7 @@ from .SCA import SpatialCrossAttn
 from .TSA import TemporalSelfAttn
 from .feedforward import FeedForwardLayer
 from .img_backbone import PatchProjection, ResNet18_wo_fpn
-from .model_utils import LayerNormProxy, TransformerMLPWithConv
+from .model_utils import LayerNormProxy, TransformerMLPWithConv, depthwise_conv2d
 
 
 class DropPath(nn.Module):
@@ -85,12 +85,12 @@ class EncoderLayer(nn.Module):
         x = bev_query
         if prev_bev is not None and not self.training:
             prev_bev = self.project_history_bev_feat(prev_bev, vehicle_pose)
-        x = x + self.tsa_local_percept_unit(x)
+        x = x + depthwise_conv2d(x, self.tsa_local_percept_unit)
         a, wandb_log_dict = self.temporal_self_attn(query=self.layer_norm(x), prev_bev=prev_bev,
                                                     wandb_log_dict=wandb_log_dict, return_wandb_log=return_wandb_log)
         x = self.drop_path(self.layer_scale(a)) + x
         x = self.drop_path(self.layer_scale(self.tsa_mlp(self.layer_norm(x)))) + x
-        x = x + self.sca_local_percept_unit(x)
+        x = x + depthwise_conv2d(x, self.sca_local_percept_unit)
         a, wandb_log_dict = self.spatial_cross_attn(query=self.layer_norm(x), img_feat=img_tensor,
                                                     vehicle_type_idx=vehicle_type_idx, wandb_log_dict=wandb_log_dict,
                                                     return_wandb_log=return_wandb_log)

@@ -5,6 +5,28 @@ import torch.nn.functional as F
 from torch import nn
 
 
+def depthwise_conv2d(x, conv: nn.Conv2d):
+    """A depthwise (groups == channels, one filter per channel) stride-1 `nn.Conv2d` evaluated as k*k shifted
+    multiply-adds.  Same arithmetic as the module; MIOpen runs the fp32 depthwise weight gradient through its
+    naive reference kernel (59 ms per call at 200x200, C = 256), while these are plain bandwidth-bound
+    elementwise passes.  Other configurations fall through to the module."""
+    k = conv.kernel_size[0]
+    if (conv.groups != conv.in_channels or conv.out_channels != conv.in_channels or conv.stride != (1, 1)
+            or conv.kernel_size != (k, k) or conv.padding != (k // 2, k // 2) or conv.dilation != (1, 1) or k % 2 == 0):
+        return conv(x)
+    H, W = x.shape[-2:]
+    xp = F.pad(x, (k // 2,) * 4)
+    w = conv.weight
+    out = None
+    for dy in range(k):
+        for dx in range(k):
+            term = xp[..., dy:dy + H, dx:dx + W] * w[:, 0, dy, dx].view(1, -1, 1, 1)
+            out = term if out is None else out + term
+    if conv.bias is not None:
+        out = out + conv.bias.view(1, -1, 1, 1)
+    return out
+
+
 class LayerNormProxy(nn.Module):
     """LayerNorm over the channel axis of an NCHW tensor (parameter path: `.norm.weight/.bias`)."""
 
@@ -33,7 +55,7 @@ class TransformerMLPWithConv(nn.Module):
 
     def forward(self, x):
         y = self.drop1(self.linear1(x))
-        y = self.act(y + self.dwc(y))
+        y = self.act(y + depthwise_conv2d(y, self.dwc))
         return self.drop2(self.linear2(y))
 
 

@@ -60,13 +60,15 @@ class SCADeformableAttention(nn.Module):
 
     @staticmethod
     def _offset_head(head, qg):
-        """The reference's offset head (1x1 depthwise C -> C*D, LayerNorm, GELU, 1x1 -> D; :56-77) with the
-        depthwise 1x1 written as the broadcast multiply it is: MIOpen runs that grouped conv's weight
-        gradient through a batched GEMM that costs 25 ms per call at 200x200."""
+        """The reference's offset head (1x1 depthwise C -> C*D, LayerNorm, GELU, 1x1 -> D; :56-77), evaluated
+        channels-last: the depthwise 1x1 is the broadcast multiply it is and the pointwise 1x1 a GEMM (MIOpen
+        runs the fp32 weight gradients of both through reference kernels: 25-61 ms per call at 200x200).
+        Returns (B*g, S, S, D)."""
         dw, norm, act, pw = head[0], head[1], head[2], head[3]
         mult = dw.out_channels // dw.in_channels
-        y = qg.repeat_interleave(mult, dim=1) * dw.weight.view(1, -1, 1, 1) + dw.bias.view(1, -1, 1, 1)
-        return pw(act(norm(y)))
+        y = qg.permute(0, 2, 3, 1).repeat_interleave(mult, dim=-1) * dw.weight.flatten() + dw.bias
+        y = F.layer_norm(y, norm.norm.normalized_shape, norm.norm.weight, norm.norm.bias, norm.norm.eps)
+        return F.linear(act(y), pw.weight.flatten(1), pw.bias)
 
     def key_positions(self, query, reference_points):
         """(B, V, g, N, 2) key positions (y, x): offset head of each view, even BEV rows -> y-offset of key
@@ -78,8 +80,9 @@ class SCADeformableAttention(nn.Module):
         ref = reference_points[..., (1, 0)]                                  # (B, V, Hk, Wk, 2) -> (y, x)
         outs = []
         for v in range(V):
-            off = self._offset_head(getattr(self, f"conv_offset_m{v}"), qg)  # (B*g, D, S, S)
-            off = off.reshape(B * g, D, Hk, 2, S).permute(0, 3, 2, 4, 1).reshape(B * g, 2, Hk, Wk)
+            off = self._offset_head(getattr(self, f"conv_offset_m{v}"), qg)  # (B*g, S, S, D) channels-last
+            # "(b g) d (h n) w -> (b g) n h (w d)", n = 2
+            off = off.reshape(B * g, Hk, 2, S, D).permute(0, 2, 1, 3, 4).reshape(B * g, 2, Hk, Wk)
             if self.scale_offset_range:
                 rng = off.new_tensor([1.0 / (Hk - 1.0), 1.0 / (Wk - 1.0)]).reshape(1, 2, 1, 1)
                 off = off.tanh() * rng * self.offset_range_factor

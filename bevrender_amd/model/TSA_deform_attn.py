@@ -67,7 +67,8 @@ class TSADeformableAttention(nn.Module):
         g = self.n_groups
         qg = query.reshape(B * g, C // g, H, W)
         co = self.conv_offset
-        off = co[3](co[2](co[1](depthwise_conv2d(qg, co[0]))))
+        y = co[2](co[1](depthwise_conv2d(qg, co[0])))                     # LayerNormProxy output: NHWC underneath
+        off = F.linear(y.permute(0, 2, 3, 1), co[3].weight.flatten(1)).permute(0, 3, 1, 2)   # 1x1 conv as a GEMM
         Hk, Wk = off.shape[-2:]
         if self.scale_offset_range:
             rng = off.new_tensor([1.0 / (Hk - 1.0), 1.0 / (Wk - 1.0)]).reshape(1, 2, 1, 1)

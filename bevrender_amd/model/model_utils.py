@@ -27,6 +27,27 @@ def depthwise_conv2d(x, conv: nn.Conv2d):
     return out
 
 
+def depthwise_conv2d_nhwc(x, conv: nn.Conv2d):
+    """depthwise_conv2d for a channels-last (B, H, W, C) tensor (stride 1, odd kernel, 'same' padding)."""
+    k = conv.kernel_size[0]
+    assert conv.groups == conv.in_channels == conv.out_channels and conv.stride == (1, 1) and k % 2 == 1
+    H, W = x.shape[1:3]
+    xp = F.pad(x, (0, 0, k // 2, k // 2, k // 2, k // 2))
+    w = conv.weight
+    out = None
+    for dy in range(k):
+        for dx in range(k):
+            term = xp[:, dy:dy + H, dx:dx + W, :] * w[:, 0, dy, dx]
+            out = term if out is None else out + term
+    return out if conv.bias is None else out + conv.bias
+
+
+def pointwise_conv_nhwc(x, conv: nn.Conv2d):
+    """A 1x1 `nn.Conv2d` applied to a channels-last tensor as the GEMM it is (rocBLAS).  MIOpen routes the fp32
+    weight gradient of these 1x1 convolutions through its naive reference kernel (61 ms per call at 200x200)."""
+    return F.linear(x, conv.weight.flatten(1), conv.bias)
+
+
 class LayerNormProxy(nn.Module):
     """LayerNorm over the channel axis of an NCHW tensor (parameter path: `.norm.weight/.bias`)."""
 
@@ -54,9 +75,11 @@ class TransformerMLPWithConv(nn.Module):
         self.dwc = nn.Conv2d(self.dim2, self.dim2, 3, 1, 1, groups=self.dim2)
 
     def forward(self, x):
-        y = self.drop1(self.linear1(x))
-        y = self.act(y + depthwise_conv2d(y, self.dwc))
-        return self.drop2(self.linear2(y))
+        xh = x.permute(0, 2, 3, 1)                                  # channels-last view (a no-copy view of the
+        y = self.drop1(pointwise_conv_nhwc(xh, self.linear1[0]))    # LayerNormProxy output that feeds this block)
+        y = self.act(y + depthwise_conv2d_nhwc(y, self.dwc))
+        y = self.drop2(pointwise_conv_nhwc(y, self.linear2[0]))
+        return y.permute(0, 3, 1, 2)
 
 
 class LayerScale(nn.Module):

@@ -5,18 +5,21 @@
 //     (preloaded into the accumulators of the two MFMA chains),
 //   * dQ^T[c][q] += K^T[c][key] dS^T[key][q] takes dS^T straight from the accumulator (B operand),
 //   * the table gradient of a (query tile x key step) block lands inside the same box the bias was read
-//     from: it is accumulated in ONE workgroup-shared LDS window of the region's shape with 64-bit
-//     fixed-point integer atomics (ds_add_u64) and flushed to HBM with contiguous float atomics only when
+//     from: it is accumulated in ONE workgroup-shared LDS window of the region's shape with fixed-point
+//     integer atomics (ds_add_u32 in bf16 mode, ds_add_u64 in f32 mode) and flushed to HBM with contiguous
+//     float atomics only when
 //     the region moves.  Measured on gfx950: LDS float atomics cost ~160 cycles per wave instruction and a
 //     plain read-modify-write needs per-wave windows, lane regrouping and ordering that pushed the kernel
 //     into scratch spills; the integer adds are cheap, order-free and make the window sums bit-reproducible.
-//     The fixed-point unit is 2^-52 of a bound on |dS| handed in by the caller (grad_scale).
+//     The fixed-point unit is 2^-30 (f32 mode) / 2^-26 (bf16 mode) of a bound on |dS| handed in by the caller
+//     (grad_scale); see AccCell.
 //     Steps whose box does not fit scatter straight to global memory with float atomics.
 // Workgroup = 16 waves (4 per SIMD, <= 128 registers each) on one 32-row x 8-column query tile: wave w owns
 // column (w & 7) and the key half (w >> 3) of every 64-key step; the two key halves' dQ partial sums are merged
 // through LDS at the end.
 // Recomputes S from Q, K and the bias instead of storing any (M x N) tensor.
 // Gradient semantics: see include/bevrender_hip.h (log2-domain inputs as handed in).
+#include <type_traits>
 #include "attn_tile.h"
 
 namespace {
@@ -34,20 +37,49 @@ template <int PREC> struct LdsQ {
   static constexpr int T_BYTES = 32 * T_STRIDE;
   static constexpr int C_BYTES = KT * 16 + 32;
   static constexpr int BUF = 2 * R_BYTES + T_BYTES + C_BYTES;
-  static constexpr int WIN = CAP * WIN_PITCH * 8;
-  static constexpr int CELLS = CAP * WIN_PITCH;   // accumulation window: one 64-bit cell per table entry
-  static constexpr int TOTAL = 2 * BUF + WIN + CELLS * 8;
+  static constexpr int ENT = PREC == BEVR_PREC_BF16 ? 4 : 8;   // table-window entry: (T[y], T[y+1]) as bf16x2 / f32x2
+  static constexpr int WCOLS = CAP + 2;           // + two "kill" columns of -1e30: where padded keys point their taps
+  static constexpr int WIN = WCOLS * WIN_PITCH * ENT;
+  static constexpr int CELLS = CAP * WIN_PITCH;   // accumulation window: one 64-bit cell per table entry (+ kill columns)
+  static constexpr int PCK = NWAVE * 32 * 16;     // per-wave (column, key) constants
+  static constexpr int ACCB = PREC == BEVR_PREC_BF16 ? 4 : 8;   // bytes per accumulation cell (see AccCell)
+  static constexpr int TOTAL = 2 * BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK;
 };
 
-// x (already multiplied by the fixed-point scale, |x| < 2^62) -> two's-complement 64-bit integer, floor rounding.
-// Exact for the float's 24 significant bits: hi = floor(x 2^-32) (exact), lo = x - hi 2^32 in [0, 2^32).
-__device__ __forceinline__ unsigned long long to_fixed64(float x) {
-  const float xh = floorf(x * 2.3283064365386963e-10f);
-  const float xl = fmaf(xh, -4294967296.0f, x);
-  const unsigned lo = (unsigned)xl;          // v_cvt_u32_f32 saturates at 2^32 - 1
-  const unsigned hi = (unsigned)(int)xh;
-  return ((unsigned long long)hi << 32) | lo;
-}
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// per-(column, key) constants, written by the owning wave once per step (lane = key), read as a broadcast
+struct ColKeyQ {
+  int cell;       // window cell (column floor(tx) - ax0) * WIN_PITCH + (floor(a) - ay0) of the first tap, lane row 0
+  float fx;       // frac(tx)
+  float fy;       // frac(a)
+  unsigned wy;    // bf16 mode: (1 - fy, fy) packed bf16x2
+};
+
+// Fixed-point accumulation cell.  A cell of a workgroup's window receives, over the life of a region, at most
+// 2 BEV rows x 8 BEV columns = 16 queries' contributions, each query's bounded by max|dS| summed over keys with
+// softmax weights (sum <= 1): |cell sum| <= 16 * bound.
+//   f32 mode : 64-bit cells, unit = bound * 2^-30   (ds_add_u64; parity mode)
+//   bf16 mode: 32-bit cells, unit = bound * 2^-26   (ds_add_u32, ~4x cheaper on gfx950; 16 * 2^26 = 2^30 fits)
+// Conversion is round-to-nearest (truncation would bias the sum of many small same-sign contributions).
+template <int PREC> struct AccCell;
+template <> struct AccCell<BEVR_PREC_F32> {
+  typedef unsigned long long type;
+  static constexpr float rescale = 1.0f;
+  static __device__ __forceinline__ type from(float x) {
+    const int v = (int)rintf(x);
+    return ((unsigned long long)(unsigned)(v >> 31) << 32) | (unsigned)v;
+  }
+  static __device__ __forceinline__ float to_float(type v) {
+    return (float)(int)(unsigned)(v >> 32) * 4294967296.0f + (float)(unsigned)v;
+  }
+};
+template <> struct AccCell<BEVR_PREC_BF16> {
+  typedef unsigned type;
+  static constexpr float rescale = 0.0625f;   // 2^-4 of the 2^30-based scale handed in
+  static __device__ __forceinline__ type from(float x) { return (unsigned)(int)rintf(x); }
+  static __device__ __forceinline__ float to_float(type v) { return (float)(int)v; }
+};
 
 template <int PREC>
 __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
@@ -59,11 +91,15 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   typedef LdsQ<PREC> L;
   constexpr int EB = L::EB;
   constexpr int CAP = L::CAP;
+  constexpr int ENT = L::ENT;
   static_assert(L::TOTAL <= 160 * 1024, "LDS budget");
   // separate LDS objects: loads of the staged tiles / table window may be scheduled across the window atomics
   __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
   __shared__ __attribute__((aligned(16))) char win[L::WIN];
-  __shared__ __attribute__((aligned(16))) unsigned long long accw[L::CELLS];
+  typedef AccCell<PREC> Acc;
+  typedef typename Acc::type acc_t;
+  __shared__ __attribute__((aligned(16))) acc_t accw[L::WCOLS * WIN_PITCH];
+  __shared__ __attribute__((aligned(16))) ColKeyQ pck_all[NWAVE * 32];
 
   const int n_rb = d.Sp / 32;
   const int n_cb = (d.S + NCOL - 1) / NCOL;
@@ -80,6 +116,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
   const int col = wave & (NCOL - 1), kh = wave / NCOL;
+  ColKeyQ* pck = pck_all + wave * 32;
   const int Mp = d.S * d.Sp;
   const int i0 = rb * 32;
 
@@ -98,7 +135,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   const int j_first = cb * NCOL;
   const int j_last = min(j_first + NCOL - 1, d.S - 1);
   const float jrx_lo = (float)j_first * rx, jrx_hi = (float)j_last * rx;
-  const float gscale = grad_scale[0], ginv = grad_scale[1];
+  const float gscale = grad_scale[0] * Acc::rescale, ginv = grad_scale[1] / Acc::rescale;
 
   // this wave's query column
   const int jcol = j_first + col;
@@ -164,6 +201,13 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
 
   stage_load(0);
   stage_store(0, 0);
+  if (tid < 2 * WIN_PITCH) {   // the two kill columns of the table window; their accumulation cells only ever get +0
+    if constexpr (PREC == BEVR_PREC_BF16)
+      *reinterpret_cast<unsigned*>(win + (CAP * WIN_PITCH + tid) * ENT) = pack_bf16x2(BEVR_NEG_BIG, BEVR_NEG_BIG);
+    else
+      *reinterpret_cast<f32x2*>(win + (CAP * WIN_PITCH + tid) * ENT) = f32x2{BEVR_NEG_BIG, BEVR_NEG_BIG};
+    accw[CAP * WIN_PITCH + tid] = 0;
+  }
   __syncthreads();
 
   Region rg;
@@ -175,11 +219,11 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   // A column of the window is 64 consecutive rows of one table column: 256-byte contiguous atomics.
   auto flush_and_clear = [&](const Region& r, bool do_flush) {
     for (int cell = tid; cell < L::CELLS; cell += TQ) {
-      const unsigned long long v = accw[cell];
-      accw[cell] = 0ull;
-      if (do_flush && v != 0ull) {
+      const acc_t v = accw[cell];
+      accw[cell] = 0;
+      if (do_flush && v != 0) {
         const int c = cell / WIN_PITCH, row = cell % WIN_PITCH;
-        const float f = ((float)(int)(unsigned)(v >> 32) * 4294967296.0f + (float)(unsigned)v) * ginv;
+        const float f = Acc::to_float(v) * ginv;
         atomicAdd(dtb + (size_t)(r.ax0 + c + d.x_off) * Hq + (size_t)(i0 + r.ay0 + d.y_off + row), f);
       }
     }
@@ -195,19 +239,40 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       // every wave finished the previous step (barrier at the end of the loop body): safe to drain and move
       flush_and_clear(rg, acc_live);
       rg = region_anchor(wi, d, i0, CAP);
-      load_region(win, tbl, d, rg, i0, CAP, NWAVE, wave, lane);
+      {   // fill the region: one wave-wide load per table column (lane = row)
+        const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
+        for (int c = wave; c < CAP; c += NWAVE) {
+          f32x2 v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)(rg.ax0 + c + d.x_off) * d.Hp + y0) * 8);
+          if constexpr (PREC == BEVR_PREC_BF16)
+            *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
+          else
+            *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = v;
+        }
+      }
       acc_live = true;
       __syncthreads();
     }
-    const float ax0_f = (float)rg.ax0;
-    const int drow = (wi.amin - rg.ay0) + lq;
+    const KeyW* kc = reinterpret_cast<const KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES) + kh * 32;
+    if (use_win) {
+      // this wave's (column, key) constants for its 32 keys of the step: lane & 31 = key (both halves write
+      // the same values); read back by this wave only -- a wave's LDS operations execute in order
+      const KeyW kw = kc[lq];
+      const float tx = jrx + (kw.b - (float)rg.ax0);
+      const float xf = floorf(tx);
+      ColKeyQ e;
+      const bool dead = step * KT + kh * 32 + lq >= d.N;   // padded key: taps in the kill column => P = 0
+      e.fx = dead ? 0.f : tx - xf;
+      e.fy = dead ? 0.f : kw.fy;
+      e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (wi.amin - rg.ay0);
+      e.wy = pack_bf16x2(1.0f - e.fy, e.fy);
+      pck[lq] = e;
+    }
 
     {
       Frag<PREC> kf, vkf, ktf;
       kf.load(base + (kh * 32 + lq) * L::R_STRIDE, hi);
       vkf.load(base + L::R_BYTES + (kh * 32 + lq) * L::R_STRIDE, hi);
       load_perm(ktf, base + 2 * L::R_BYTES + lq * L::T_STRIDE + kh * 32 * EB, hi);
-      const KeyW* kc = reinterpret_cast<const KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES) + kh * 32;
       const bool last = (step == n_step - 1) && d.N < d.Np;
 
       f32x16 s, dp;
@@ -219,31 +284,35 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       if (use_win) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const KeyW c = kc[crow(r, hi)];
-          const float wy0 = 1.0f - c.fy;
-          float tx = jrx + (c.b - ax0_f);
-          float xf = floorf(tx);
-          float fx = tx - xf;
-          const int xi = (int)xf;
-          const int row = (c.arow8 >> 3) + drow;
-          const int cell = xi * WIN_PITCH + row;
-          const char* p = win + cell * 8;
-          f32x2 t0 = *reinterpret_cast<const f32x2*>(p);
-          f32x2 t1 = *reinterpret_cast<const f32x2*>(p + WIN_PITCH * 8);
-          float u0 = t0[0] * wy0 + t0[1] * c.fy;
-          float u1 = t1[0] * wy0 + t1[1] * c.fy;
-          float sv = s[r] + u0 + fx * (u1 - u0);
-          if (last && step * KT + kh * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
-          float ds = BEVR_LN2 * fast_exp2(sv) * dp[r];
+          const ColKeyQ e = pck[crow(r, hi)];
+          const int cell = e.cell + lq;
+          const char* p = win + cell * ENT;
+          float u0, u1;
+          if constexpr (PREC == BEVR_PREC_BF16) {
+            const bf16x2 wy = __builtin_bit_cast(bf16x2, e.wy);
+            u0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, *reinterpret_cast<const unsigned*>(p)), wy, 0.f,
+                                                 false);
+            u1 = __builtin_amdgcn_fdot2_f32_bf16(
+                __builtin_bit_cast(bf16x2, *reinterpret_cast<const unsigned*>(p + WIN_PITCH * ENT)), wy, 0.f, false);
+          } else {
+            const f32x2 t0 = *reinterpret_cast<const f32x2*>(p);
+            const f32x2 t1 = *reinterpret_cast<const f32x2*>(p + WIN_PITCH * ENT);
+            u0 = t0[0] * (1.0f - e.fy) + t0[1] * e.fy;
+            u1 = t1[0] * (1.0f - e.fy) + t1[1] * e.fy;
+          }
+          const float omfx = 1.0f - e.fx;
+          const float sv = fmaf(u1, e.fx, fmaf(u0, omfx, s[r]));   // padded keys: -1e30 from the kill column
+          const float ds = BEVR_LN2 * fast_exp2(sv) * dp[r];
           s[r] = ds;
           // table gradient: four fixed-point adds into the shared window (order-free, so no per-wave windows)
           const float dss = ds * gscale;
-          const float w0 = dss * (1.0f - fx), w1 = dss * fx;
-          unsigned long long* g = accw + cell;
-          atomicAdd(g, to_fixed64(w0 * wy0));
-          atomicAdd(g + 1, to_fixed64(w0 * c.fy));
-          atomicAdd(g + WIN_PITCH, to_fixed64(w1 * wy0));
-          atomicAdd(g + WIN_PITCH + 1, to_fixed64(w1 * c.fy));
+          const float w0 = dss * omfx, w1 = dss * e.fx;
+          const float c01 = w0 * e.fy, c11 = w1 * e.fy;
+          acc_t* g = accw + cell;
+          atomicAdd(g, Acc::from(w0 - c01));
+          atomicAdd(g + 1, Acc::from(c01));
+          atomicAdd(g + WIN_PITCH, Acc::from(w1 - c11));
+          atomicAdd(g + WIN_PITCH + 1, Acc::from(c11));
         }
       } else {
 #pragma unroll

@@ -270,9 +270,9 @@ class _AttnCore(torch.autograd.Function):
         dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
         Kt = _perm_t(Ke)
         # fixed-point scale of the in-LDS table-gradient accumulation (include/bevrender_hip.h): a power of two
-        # s with s * bound(|dS|) <= 2^52, bound = ln2 * 64 * max|dO| * max|V|.  Stays on the device (no sync).
+        # s with s * bound(|dS|) <= 2^30, bound = ln2 * 64 * max|dO| * max|V|.  Stays on the device (no sync).
         bound = (math.log(2.0) * 2 * HEAD_DIM) * dOe.abs().max().float() * Ve.abs().max().float()
-        e = torch.floor(52.0 - torch.log2(bound.clamp_min(1e-30))).clamp(-100.0, 100.0)
+        e = torch.floor(30.0 - torch.log2(bound.clamp_min(1e-30))).clamp(-100.0, 100.0)
         gscale = torch.stack((torch.exp2(e), torch.exp2(-e))).contiguous()
         _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(geom, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
                                     _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_a), _ptr(key_b), _ptr(pair), _ptr(dOe),

@@ -104,9 +104,10 @@ int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const v
  *   it is ACCUMULATED into (caller zeroes it).
  *   V  [n_prob][heads][Np][32] E (row layout), Kt [like Vt] E, dO [n_prob][heads][Mp][32] E,
  *   delta [n_prob][heads][Mp] float = rowsum(dO * O).
- *   grad_scale [2] float (device): { s, 1/s } with s a power of two such that s * max|dS| <= 2^52, where
+ *   grad_scale [2] float (device): { s, 1/s } with s a power of two such that s * max|dS| <= 2^30, where
  *   dS = ln2 * P * (dP - delta) is bounded by ln2 * 64 * max|dO| * max|V| (head_dim 32, P <= 1, O a convex
- *   combination of V).  The kernel accumulates the table gradient in 64-bit fixed point with unit 1/s.
+ *   combination of V).  The kernel accumulates the table gradient in 64-bit fixed point with unit 1/s
+ *   (round to nearest; sums are exact and order-independent within a workgroup's window).
  *   All gradients are with respect to the log2-domain logits' inputs as handed in (Q pre-scaled,
  *   table pre-multiplied): the caller's autograd undoes the scaling. */
 int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,

@@ -22,6 +22,26 @@
 #include <type_traits>
 #include "attn_tile.h"
 
+#ifdef BEVR_PROF
+__device__ unsigned long long bevr_prof[16];
+extern "C" int bevr_debug_prof(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(bevr_prof), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bevr_prof), 16 * 8);
+}
+__device__ __forceinline__ unsigned long long prof_now(float dep) {
+  unsigned long long t;
+  asm volatile("s_nop 0\n s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  return t;
+}
+#define PROF_T(var) const unsigned long long var = prof_now(0.f)
+#define PROF_TD(var, dep) const unsigned long long var = prof_now(dep)
+#define PROF_ADD(i, v) pacc[i] += (v)
+#else
+#define PROF_T(var)
+#define PROF_TD(var, dep)
+#define PROF_ADD(i, v)
+#endif
+
 namespace {
 
 constexpr int TQ = 1024;  // threads per workgroup
@@ -41,7 +61,7 @@ template <int PREC> struct LdsQ {
   static constexpr int WCOLS = CAP + 2;           // + two "kill" columns of -1e30: where padded keys point their taps
   static constexpr int WIN = WCOLS * WIN_PITCH * ENT;
   static constexpr int CELLS = CAP * WIN_PITCH;   // accumulation window: one 64-bit cell per table entry (+ kill columns)
-  static constexpr int PCK = NWAVE * 32 * 16;     // per-wave (column, key) constants
+  static constexpr int PCK = NWAVE * 32 * 32;     // per-wave (column, key) constants
   static constexpr int ACCB = PREC == BEVR_PREC_BF16 ? 4 : 8;   // bytes per accumulation cell (see AccCell)
   static constexpr int TOTAL = 2 * BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK;
 };
@@ -50,11 +70,19 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 // per-(column, key) constants, written by the owning wave once per step (lane = key), read as a broadcast
 struct ColKeyQ {
-  int cell;       // window cell (column floor(tx) - ax0) * WIN_PITCH + (floor(a) - ay0) of the first tap, lane row 0
-  float fx;       // frac(tx)
-  float fy;       // frac(a)
-  unsigned wy;    // bf16 mode: (1 - fy, fy) packed bf16x2
+  int cell;         // window cell (column floor(tx) - ax0) * WIN_PITCH + (floor(a) - ay0) of the first tap, lane row 0
+  unsigned wA, wB;  // bf16 mode: the tap weights of column x / x + 1 as packed bf16x2 (row y, row y + 1)
+  unsigned pad;
+  float w00, w01, w10, w11;   // (1-fx)(1-fy), (1-fx)fy, fx(1-fy), fx fy
 };
+static_assert(sizeof(ColKeyQ) == 32, "two 16-byte broadcast reads");
+
+// round-to-nearest float -> int in one instruction (floor(x + 0.5))
+__device__ __forceinline__ int cvt_rpi(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 
 // Fixed-point accumulation cell.  A cell of a workgroup's window receives, over the life of a region, at most
 // 2 BEV rows x 8 BEV columns = 16 queries' contributions, each query's bounded by max|dS| summed over keys with
@@ -67,7 +95,7 @@ template <> struct AccCell<BEVR_PREC_F32> {
   typedef unsigned long long type;
   static constexpr float rescale = 1.0f;
   static __device__ __forceinline__ type from(float x) {
-    const int v = (int)rintf(x);
+    const int v = cvt_rpi(x);
     return ((unsigned long long)(unsigned)(v >> 31) << 32) | (unsigned)v;
   }
   static __device__ __forceinline__ float to_float(type v) {
@@ -77,7 +105,7 @@ template <> struct AccCell<BEVR_PREC_F32> {
 template <> struct AccCell<BEVR_PREC_BF16> {
   typedef unsigned type;
   static constexpr float rescale = 0.0625f;   // 2^-4 of the 2^30-based scale handed in
-  static __device__ __forceinline__ type from(float x) { return (unsigned)(int)rintf(x); }
+  static __device__ __forceinline__ type from(float x) { return (unsigned)cvt_rpi(x); }
   static __device__ __forceinline__ float to_float(type v) { return (float)(int)v; }
 };
 
@@ -135,7 +163,8 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   const int j_first = cb * NCOL;
   const int j_last = min(j_first + NCOL - 1, d.S - 1);
   const float jrx_lo = (float)j_first * rx, jrx_hi = (float)j_last * rx;
-  const float gscale = grad_scale[0] * Acc::rescale, ginv = grad_scale[1] / Acc::rescale;
+  // dS = ln2 * P * (dP - delta): the ln2 is folded into the fixed-point scale here and into dQ at the end
+  const float gscale = grad_scale[0] * Acc::rescale * BEVR_LN2, ginv = grad_scale[1] / Acc::rescale;
 
   // this wave's query column
   const int jcol = j_first + col;
@@ -169,33 +198,54 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   constexpr int RCH_ROW = 32 * EB / 16;
   constexpr int TCH_ROW = KT * EB / 16;
   constexpr int CH = KT * RCH_ROW;            // 16-B chunks per tile: 256 (bf16) / 512 (f32)
-  static_assert(CH <= TQ, "one chunk per thread per tile");
-  u32x4 stK, stV, stT;
+  // staging: the 3 CH chunks of the K, V and Kt tiles are dealt over the first TQ - 64 threads (1 chunk each in
+  // bf16 mode, 2 in f32 mode); the last wave carries the 64 keys' coordinates and does the bounding-box
+  // reductions, off the tile waves' path
+  constexpr int NST = TQ - 64;
+  constexpr int NCHK = (3 * CH + NST - 1) / NST;
+  u32x4 st[NCHK];
   float st_a = 0.f, st_b = 0.f;
   const int n_step = d.Np / KT;
+  const int kt = tid - NST;   // key slot of the last wave's lanes
+  // per-thread source pointer (advanced by a fixed stride per step) and LDS destination offset of each chunk
+  const char* st_src[NCHK];
+  int st_inc[NCHK], st_dst[NCHK];
+#pragma unroll
+  for (int k = 0; k < NCHK; ++k) {
+    const int g = tid + k * NST;
+    const int kind = g / CH, ci = g % CH;
+    if (kind < 2) {
+      st_src[k] = (kind ? Vh : Kh) + (size_t)ci * 16;
+      st_inc[k] = CH * 16;
+      st_dst[k] = kind * L::R_BYTES + (ci / RCH_ROW) * L::R_STRIDE + (ci % RCH_ROW) * 16;
+    } else {
+      st_src[k] = Kth + ((size_t)(ci / TCH_ROW) * d.Np) * EB + (ci % TCH_ROW) * 16;
+      st_inc[k] = KT * EB;
+      st_dst[k] = 2 * L::R_BYTES + (ci / TCH_ROW) * L::T_STRIDE + (ci % TCH_ROW) * 16;
+    }
+    if (kt >= 0 || kind > 2) st_dst[k] = -1;   // not a tile thread / past the last chunk
+  }
+  const float* st_ka = ka + max(kt, 0);
+  const float* st_kb = kb + max(kt, 0);
 
   auto stage_load = [&](int step) {
-    if (tid < CH) {
-      stK = *reinterpret_cast<const u32x4*>(Kh + ((size_t)step * CH + tid) * 16);
-      stV = *reinterpret_cast<const u32x4*>(Vh + ((size_t)step * CH + tid) * 16);
-      int tr = tid / TCH_ROW, tc = tid % TCH_ROW;
-      stT = *reinterpret_cast<const u32x4*>(Kth + ((size_t)tr * d.Np + (size_t)step * KT) * EB + tc * 16);
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) {
+      if (st_dst[k] >= 0) st[k] = *reinterpret_cast<const u32x4*>(st_src[k]);
+      st_src[k] += st_inc[k];
     }
-    if (tid < KT) { st_a = ka[step * KT + tid]; st_b = kb[step * KT + tid]; }
+    if (kt >= 0) { st_a = st_ka[step * KT]; st_b = st_kb[step * KT]; }
   };
   auto stage_store = [&](int buf, int step) {
     char* base = smem + buf * L::BUF;
-    if (tid < CH) {
-      int ro = (tid / RCH_ROW) * L::R_STRIDE + (tid % RCH_ROW) * 16;
-      *reinterpret_cast<u32x4*>(base + ro) = stK;
-      *reinterpret_cast<u32x4*>(base + L::R_BYTES + ro) = stV;
-      *reinterpret_cast<u32x4*>(base + 2 * L::R_BYTES + (tid / TCH_ROW) * L::T_STRIDE + (tid % TCH_ROW) * 16) = stT;
-    }
-    if (tid < KT) {   // exactly wave 0
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k)
+      if (st_dst[k] >= 0) *reinterpret_cast<u32x4*>(base + st_dst[k]) = st[k];
+    if (kt >= 0) {   // exactly the last wave
       WinInfo wi;
-      KeyW kw = stage_keys(st_a, st_b, step * KT + tid < d.N, d, jrx_lo, jrx_hi, CAP, wi);
-      *reinterpret_cast<KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES + tid * 16) = kw;
-      if (tid == 0) *reinterpret_cast<WinInfo*>(base + 2 * L::R_BYTES + L::T_BYTES + KT * 16) = wi;
+      KeyW kw = stage_keys(st_a, st_b, step * KT + kt < d.N, d, jrx_lo, jrx_hi, CAP, wi);
+      *reinterpret_cast<KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES + kt * 16) = kw;
+      if (kt == 0) *reinterpret_cast<WinInfo*>(base + 2 * L::R_BYTES + L::T_BYTES + KT * 16) = wi;
     }
   };
 
@@ -229,7 +279,11 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     }
   };
 
+#ifdef BEVR_PROF
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int step = 0; step < n_step; ++step) {
+    PROF_T(t0);
     const int buf = step & 1;
     const char* base = smem + buf * L::BUF;
     if (step + 1 < n_step) stage_load(step + 1);
@@ -251,7 +305,10 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       }
       acc_live = true;
       __syncthreads();
+      PROF_ADD(5, 1);
     }
+    PROF_T(t1);
+    PROF_ADD(0, t1 - t0);
     const KeyW* kc = reinterpret_cast<const KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES) + kh * 32;
     if (use_win) {
       // this wave's (column, key) constants for its 32 keys of the step: lane & 31 = key (both halves write
@@ -261,10 +318,15 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       const float xf = floorf(tx);
       ColKeyQ e;
       const bool dead = step * KT + kh * 32 + lq >= d.N;   // padded key: taps in the kill column => P = 0
-      e.fx = dead ? 0.f : tx - xf;
-      e.fy = dead ? 0.f : kw.fy;
+      const float fx = tx - xf, fy = kw.fy;
+      e.w00 = dead ? 1.f : (1.0f - fx) * (1.0f - fy);
+      e.w01 = dead ? 0.f : (1.0f - fx) * fy;
+      e.w10 = dead ? 0.f : fx * (1.0f - fy);
+      e.w11 = dead ? 0.f : fx * fy;
       e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (wi.amin - rg.ay0);
-      e.wy = pack_bf16x2(1.0f - e.fy, e.fy);
+      e.wA = pack_bf16x2(e.w00, e.w01);
+      e.wB = pack_bf16x2(e.w10, e.w11);
+      e.pad = 0;
       pck[lq] = e;
     }
 
@@ -276,43 +338,57 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       const bool last = (step == n_step - 1) && d.N < d.Np;
 
       f32x16 s, dp;
+      {
+        // launder the row constants: otherwise the splatted 16-register accumulator seeds are hoisted out of the
+        // step loop and live in scratch (reloaded every step, a full-latency miss each time)
+        float nl = -lse, nd = -dlt;
+        asm volatile("" : "+v"(nl), "+v"(nd));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = -lse; dp[r] = -dlt; }
+        for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
+      }
       s = mma_frag(kf, qf, s);       // S^T - LSE
       dp = mma_frag(vkf, dof, dp);   // dP^T - delta
+      PROF_TD(t2, s[0] + dp[15]);
+      PROF_ADD(1, t2 - t1);
 
       if (use_win) {
+        // The LDS atomics are ordered memory operations for the compiler: it moves no load across them.  So
+        // the loop is software-pipelined by hand -- the taps of key r + 1 and the constants of key r + 2 are
+        // requested before the atomics of key r are issued, and their latency hides behind key r's arithmetic.
+        typedef typename std::conditional<PREC == BEVR_PREC_BF16, unsigned, f32x2>::type tap_t;
+        auto read_tap = [&](int cell, tap_t& a, tap_t& b) {
+          const char* p = win + (cell + lq) * ENT;
+          a = *reinterpret_cast<const tap_t*>(p);
+          b = *reinterpret_cast<const tap_t*>(p + WIN_PITCH * ENT);
+        };
+        ColKeyQ e0 = pck[crow(0, hi)], e1 = pck[crow(1, hi)];
+        tap_t ta, tb;
+        read_tap(e0.cell, ta, tb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const ColKeyQ e = pck[crow(r, hi)];
-          const int cell = e.cell + lq;
-          const char* p = win + cell * ENT;
-          float u0, u1;
+          tap_t na = ta, nb = tb;
+          ColKeyQ e2 = e1;
+          if (r + 1 < 16) read_tap(e1.cell, na, nb);
+          if (r + 2 < 16) e2 = pck[crow(r + 2, hi)];
+          float sv;
           if constexpr (PREC == BEVR_PREC_BF16) {
-            const bf16x2 wy = __builtin_bit_cast(bf16x2, e.wy);
-            u0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, *reinterpret_cast<const unsigned*>(p)), wy, 0.f,
+            sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ta), __builtin_bit_cast(bf16x2, e0.wA), s[r],
                                                  false);
-            u1 = __builtin_amdgcn_fdot2_f32_bf16(
-                __builtin_bit_cast(bf16x2, *reinterpret_cast<const unsigned*>(p + WIN_PITCH * ENT)), wy, 0.f, false);
+            sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, tb), __builtin_bit_cast(bf16x2, e0.wB), sv,
+                                                 false);
           } else {
-            const f32x2 t0 = *reinterpret_cast<const f32x2*>(p);
-            const f32x2 t1 = *reinterpret_cast<const f32x2*>(p + WIN_PITCH * ENT);
-            u0 = t0[0] * (1.0f - e.fy) + t0[1] * e.fy;
-            u1 = t1[0] * (1.0f - e.fy) + t1[1] * e.fy;
+            sv = fmaf(tb[1], e0.w11, fmaf(tb[0], e0.w10, fmaf(ta[1], e0.w01, fmaf(ta[0], e0.w00, s[r]))));
           }
-          const float omfx = 1.0f - e.fx;
-          const float sv = fmaf(u1, e.fx, fmaf(u0, omfx, s[r]));   // padded keys: -1e30 from the kill column
-          const float ds = BEVR_LN2 * fast_exp2(sv) * dp[r];
+          const float ds = fast_exp2(sv) * dp[r];   // padded keys: -1e30 from the kill column => 0
           s[r] = ds;
           // table gradient: four fixed-point adds into the shared window (order-free, so no per-wave windows)
           const float dss = ds * gscale;
-          const float w0 = dss * omfx, w1 = dss * e.fx;
-          const float c01 = w0 * e.fy, c11 = w1 * e.fy;
-          acc_t* g = accw + cell;
-          atomicAdd(g, Acc::from(w0 - c01));
-          atomicAdd(g + 1, Acc::from(c01));
-          atomicAdd(g + WIN_PITCH, Acc::from(w1 - c11));
-          atomicAdd(g + WIN_PITCH + 1, Acc::from(c11));
+          acc_t* g = accw + (e0.cell + lq);
+          atomicAdd(g, Acc::from(dss * e0.w00));
+          atomicAdd(g + 1, Acc::from(dss * e0.w01));
+          atomicAdd(g + WIN_PITCH, Acc::from(dss * e0.w10));
+          atomicAdd(g + WIN_PITCH + 1, Acc::from(dss * e0.w11));
+          e0 = e1; e1 = e2; ta = na; tb = nb;
         }
       } else {
 #pragma unroll
@@ -330,13 +406,13 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
           float u1 = t1[0] * wy0 + t1[1] * c.fy;
           float sv = s[r] + u0 + fx * (u1 - u0);
           if (last && step * KT + kh * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
-          float ds = BEVR_LN2 * fast_exp2(sv) * dp[r];
+          float ds = fast_exp2(sv) * dp[r];
           s[r] = ds;
           if (ds != 0.f) {
             // plain transposed table, row pitch Hp + 1
             int yi = (c.aoff >> 3) - xoffHp + ilane;
             float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
-            float w0 = ds * (1.0f - fx), w1 = ds * fx;
+            float w0 = BEVR_LN2 * ds * (1.0f - fx), w1 = BEVR_LN2 * ds * fx;
             atomicAdd(g0, w0 * wy0);
             atomicAdd(g0 + 1, w0 * c.fy);
             atomicAdd(g0 + Hq, w1 * wy0);
@@ -344,12 +420,26 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
           }
         }
       }
+      PROF_TD(t3, s[15]);
+      PROF_ADD(2, t3 - t2);
       dq = mma_acc_b(ktf, s, dq);
+      PROF_TD(t3b, dq[0]);
+      PROF_ADD(6, t3b - t3);
     }
 
     if (step + 1 < n_step) stage_store(buf ^ 1, step + 1);
+    PROF_T(t4);
     __syncthreads();
+    PROF_T(t5);
+    PROF_ADD(3, t4 - t1);
+    PROF_ADD(4, t5 - t4);
+    PROF_ADD(7, 1);
   }
+#ifdef BEVR_PROF
+  if (lane == 0 && (wave == 0 || wave == 15)) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof[(wave ? 8 : 0) + i], pacc[i]);
+  }
+#endif
   flush_and_clear(rg, acc_live);
 
   // ---- merge the two key halves' dQ partial sums (waves w and w + 8) through LDS, then store ------------
@@ -371,7 +461,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = dq[4 * g4 + k] + *xptr(col, 4 * g4 + k);
+      for (int k = 0; k < 4; ++k) v[k] = BEVR_LN2 * (dq[4 * g4 + k] + *xptr(col, 4 * g4 + k));
       *reinterpret_cast<f32x4*>(row + 8 * g4 + 4 * hi) = v;
     }
   }

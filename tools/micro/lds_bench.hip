@@ -1,0 +1,58 @@
+// Micro-benchmark: LDS instruction throughput per CU on gfx950 (16 waves per CU, conflict-free addresses).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+template <int MODE>
+__global__ __launch_bounds__(1024) void k(int iters, unsigned* out, int stride) {
+  __shared__ unsigned a[16384];
+  __shared__ unsigned long long b[8192];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 16384; i += 1024) a[i] = 0;
+  for (int i = tid; i < 8192; i += 1024) b[i] = 0;
+  __syncthreads();
+  unsigned acc = 0;
+  const int wave = tid >> 6, lane = tid & 63;
+  int idx = (wave * 64 * stride + lane * stride) & 8191;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = (idx + u * 64) & 8191;
+      if (MODE == 0) atomicAdd(&a[j], (unsigned)it);
+      else if (MODE == 1) atomicAdd(&b[j], (unsigned long long)it);
+      else if (MODE == 2) atomicAdd(reinterpret_cast<float*>(&a[j]), 1.0f);
+      else if (MODE == 3) { a[j] = it; asm volatile("" ::: "memory"); }
+      else if (MODE == 4) { acc += a[j]; asm volatile("" ::: "memory"); }
+      else if (MODE == 5) { acc += (unsigned)b[j]; asm volatile("" ::: "memory"); }
+      else if (MODE == 6) { unsigned v = it; asm volatile("ds_add_u32 %0, %1" :: "v"(j * 4), "v"(v) : "memory"); }
+    }
+  }
+  if (MODE == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  out[blockIdx.x * 1024 + tid] = acc + a[tid] + (unsigned)b[tid];
+}
+template <int MODE> void run(const char* name, int stride) {
+  unsigned* out; hipMalloc(&out, 1024 * 1024 * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int iters = 2000, grid = 256;
+  k<MODE><<<grid, 1024>>>(10, out, stride);
+  hipEventRecord(e0);
+  k<MODE><<<grid, 1024>>>(iters, out, stride);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  double instr_per_cu = (double)iters * 8 * 16;   // wave instructions per CU
+  printf("%-28s stride %d: %.3f ms, %.2f ns per wave-instr per CU (= %.1f clk @2.4GHz)\n", name, stride, ms,
+         ms * 1e6 / instr_per_cu, ms * 1e6 / instr_per_cu * 2.4);
+  hipFree(out);
+}
+int main() {
+  for (int stride = 1; stride <= 2; ++stride) {
+    run<0>("atomicAdd u32", stride);
+    run<6>("ds_add_u32 asm noret", stride);
+    run<1>("atomicAdd u64", stride);
+    run<2>("atomicAdd f32", stride);
+    run<3>("store b32", stride);
+    run<4>("load b32", stride);
+    run<5>("load b64", stride);
+  }
+  return 0;
+}

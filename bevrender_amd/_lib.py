@@ -22,7 +22,8 @@ PREC_F32, PREC_BF16 = 0, 1
 
 # every symbol include/bevrender_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "bevr_abi_version", "bevr_strerror", "bevr_attn_table_dims", "bevr_attn_fwd", "bevr_attn_bwd_q",
+    "bevr_abi_version", "bevr_strerror", "bevr_attn_table_dims", "bevr_attn_key_ws_bytes", "bevr_attn_key_prep",
+    "bevr_attn_fwd", "bevr_attn_bwd_q",
     "bevr_attn_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_project_bev_grid", "bevr_corr_fwd",
     "bevr_corr_bwd", "bevr_recall_rank",
 ]
@@ -74,8 +75,10 @@ def lib() -> C.CDLL:
         L.bevr_strerror.restype = C.c_char_p
         L.bevr_strerror.argtypes = [C.c_int]
         L.bevr_attn_table_dims.argtypes = [dp]
-        L.bevr_attn_fwd.argtypes = [dp, vp, vp, vp, fp, fp, fp, fp, fp, vp]
-        L.bevr_attn_bwd_q.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, fp, fp, fp, fp, fp, vp]
+        L.bevr_attn_key_ws_bytes.argtypes = [dp]
+        L.bevr_attn_key_prep.argtypes = [dp, fp, fp, vp, vp]
+        L.bevr_attn_fwd.argtypes = [dp, vp, vp, vp, vp, fp, fp, fp, vp]
+        L.bevr_attn_bwd_q.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, fp, fp, fp, fp, fp, vp]
         L.bevr_attn_bwd_k.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, vp, fp, fp] + [fp] * 4 + [vp]
         L.bevr_sample_fwd.argtypes = [fp, fp, fp] + [ip] * 5 + [vp]
         L.bevr_sample_bwd.argtypes = [fp] * 5 + [ip] * 5 + [vp]
@@ -85,9 +88,11 @@ def lib() -> C.CDLL:
         L.bevr_recall_rank.argtypes = [fp, vp, ip, vp]
         for name in SYMBOLS:
             fn = getattr(L, name)
-            if name not in ("bevr_strerror",):
+            if name == "bevr_attn_key_ws_bytes":
+                fn.restype = C.c_size_t
+            elif name not in ("bevr_strerror",):
                 fn.restype = C.c_int
-        if L.bevr_abi_version() != 1:
+        if L.bevr_abi_version() != 2:
             raise BevrError("libbevrender_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -61,21 +61,46 @@ template <int PREC> struct LdsQ {
   static constexpr int WCOLS = CAP + 2;           // + two "kill" columns of -1e30: where padded keys point their taps
   static constexpr int WIN = WCOLS * WIN_PITCH * ENT;
   static constexpr int CELLS = CAP * WIN_PITCH;   // accumulation window: one 64-bit cell per table entry (+ kill columns)
-  static constexpr int PCK = NWAVE * 32 * 32;     // per-wave (column, key) constants
+  static constexpr int PCK = NWAVE * 32 * (PREC == BEVR_PREC_BF16 ? 16 : 32);
+  // bf16 mode: the tile's Q and dO fragments live in LDS (fragment order, re-read every step) instead of 16 registers
+  static constexpr int QDO = PREC == BEVR_PREC_BF16 ? NCOL * 4 * 64 * 16 : 16;     // per-wave (column, key) constants
   static constexpr int ACCB = PREC == BEVR_PREC_BF16 ? 4 : 8;   // bytes per accumulation cell (see AccCell)
-  static constexpr int TOTAL = 2 * BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK;
+  static constexpr int TOTAL = 2 * BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK + QDO;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
-// per-(column, key) constants, written by the owning wave once per step (lane = key), read as a broadcast
-struct ColKeyQ {
+// per-(column, key) constants, written by the owning wave once per step (lane = key), read as a broadcast.
+// bf16 mode keeps only the packed bf16 tap weights (the gradient unpacks them: the weights the bias was computed
+// with); f32 mode keeps them in full precision.
+template <int PREC> struct ColKeyQ;
+template <> struct ColKeyQ<BEVR_PREC_BF16> {
   int cell;         // window cell (column floor(tx) - ax0) * WIN_PITCH + (floor(a) - ay0) of the first tap, lane row 0
-  unsigned wA, wB;  // bf16 mode: the tap weights of column x / x + 1 as packed bf16x2 (row y, row y + 1)
+  unsigned wA, wB;  // tap weights of column x / x + 1 as packed bf16x2 (row y, row y + 1)
   unsigned pad;
-  float w00, w01, w10, w11;   // (1-fx)(1-fy), (1-fx)fy, fx(1-fy), fx fy
+  __device__ __forceinline__ void set(float w00, float w01, float w10, float w11) {
+    wA = pack_bf16x2(w00, w01);
+    wB = pack_bf16x2(w10, w11);
+    pad = 0;
+  }
+  __device__ __forceinline__ float w00() const { return __builtin_bit_cast(float, wA << 16); }
+  __device__ __forceinline__ float w01() const { return __builtin_bit_cast(float, wA & 0xffff0000u); }
+  __device__ __forceinline__ float w10() const { return __builtin_bit_cast(float, wB << 16); }
+  __device__ __forceinline__ float w11() const { return __builtin_bit_cast(float, wB & 0xffff0000u); }
 };
-static_assert(sizeof(ColKeyQ) == 32, "two 16-byte broadcast reads");
+template <> struct ColKeyQ<BEVR_PREC_F32> {
+  int cell;
+  unsigned pad0, pad1, pad2;
+  float f00, f01, f10, f11;   // (1-fx)(1-fy), (1-fx)fy, fx(1-fy), fx fy
+  __device__ __forceinline__ void set(float w00, float w01, float w10, float w11) {
+    f00 = w00; f01 = w01; f10 = w10; f11 = w11;
+    pad0 = pad1 = pad2 = 0;
+  }
+  __device__ __forceinline__ float w00() const { return f00; }
+  __device__ __forceinline__ float w01() const { return f01; }
+  __device__ __forceinline__ float w10() const { return f10; }
+  __device__ __forceinline__ float w11() const { return f11; }
+};
 
 // round-to-nearest float -> int in one instruction (floor(x + 0.5))
 __device__ __forceinline__ int cvt_rpi(float x) {
@@ -112,7 +137,7 @@ template <> struct AccCell<BEVR_PREC_BF16> {
 template <int PREC>
 __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Kt,
-    const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
+    const char* __restrict__ V, const char* __restrict__ key_ws,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const float* __restrict__ LSE,
     const float* __restrict__ delta, const float* __restrict__ grad_scale, float* __restrict__ dQ,
     float* __restrict__ dtable) {
@@ -127,7 +152,9 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   typedef AccCell<PREC> Acc;
   typedef typename Acc::type acc_t;
   __shared__ __attribute__((aligned(16))) acc_t accw[L::WCOLS * WIN_PITCH];
-  __shared__ __attribute__((aligned(16))) ColKeyQ pck_all[NWAVE * 32];
+  typedef ColKeyQ<PREC> CK;
+  __shared__ __attribute__((aligned(16))) CK pck_all[NWAVE * 32];
+  __shared__ __attribute__((aligned(16))) char qdo[L::QDO];
 
   const int n_rb = d.Sp / 32;
   const int n_cb = (d.S + NCOL - 1) / NCOL;
@@ -144,7 +171,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
   const int col = wave & (NCOL - 1), kh = wave / NCOL;
-  ColKeyQ* pck = pck_all + wave * 32;
+  CK* pck = pck_all + wave * 32;
   const int Mp = d.S * d.Sp;
   const int i0 = rb * 32;
 
@@ -153,8 +180,9 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   const char* Kh = K + ((size_t)ph * d.Np) * 32 * EB;
   const char* Vh = V + ((size_t)ph * d.Np) * 32 * EB;
   const char* Kth = Kt + ((size_t)ph * 32) * d.Np * EB;
-  const float* ka = key_a + (size_t)(prob * d.groups + grp) * d.Np;
-  const float* kb = key_b + (size_t)(prob * d.groups + grp) * d.Np;
+  const int pg = prob * d.groups + grp;
+  const KeyW* kws = reinterpret_cast<const KeyW*>(key_ws) + (size_t)pg * d.Np;
+  const StepBox* kbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / KT);
   const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
   float* dtb = dtable + (size_t)hd * d.Wp * (d.Hp + 1);
   const int Hp8 = d.Hp * 8;
@@ -187,6 +215,15 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     }
     dlt = 0.f;
   }
+  if constexpr (PREC == BEVR_PREC_BF16) {
+    if (kh == 0) {
+      u32x4* qd = reinterpret_cast<u32x4*>(qdo) + col * 4 * 64 + lane;
+      qd[0] = __builtin_bit_cast(u32x4, qf.v[0]);
+      qd[64] = __builtin_bit_cast(u32x4, qf.v[1]);
+      qd[128] = __builtin_bit_cast(u32x4, dof.v[0]);
+      qd[192] = __builtin_bit_cast(u32x4, dof.v[1]);
+    }
+  }
   const int ilane = i0 + lq;
   const int rowoff = ilane * 8;
   const int xoffHp = d.x_off * d.Hp;
@@ -198,35 +235,33 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   constexpr int RCH_ROW = 32 * EB / 16;
   constexpr int TCH_ROW = KT * EB / 16;
   constexpr int CH = KT * RCH_ROW;            // 16-B chunks per tile: 256 (bf16) / 512 (f32)
-  // staging: the 3 CH chunks of the K, V and Kt tiles are dealt over the first TQ - 64 threads (1 chunk each in
-  // bf16 mode, 2 in f32 mode); the last wave carries the 64 keys' coordinates and does the bounding-box
-  // reductions, off the tile waves' path
-  constexpr int NST = TQ - 64;
-  constexpr int NCHK = (3 * CH + NST - 1) / NST;
+  // staging: the 3 CH chunks of the K, V and Kt tiles plus the 64 KeyW records of the step are dealt over the
+  // threads (1 chunk each in bf16 mode, 2 in f32 mode): per-thread source pointer (advanced by a fixed stride
+  // per step) and LDS destination offset of each chunk
+  constexpr int NCHUNK = 3 * CH + KT;
+  constexpr int NCHK = (NCHUNK + TQ - 1) / TQ;
   u32x4 st[NCHK];
-  float st_a = 0.f, st_b = 0.f;
   const int n_step = d.Np / KT;
-  const int kt = tid - NST;   // key slot of the last wave's lanes
-  // per-thread source pointer (advanced by a fixed stride per step) and LDS destination offset of each chunk
   const char* st_src[NCHK];
   int st_inc[NCHK], st_dst[NCHK];
 #pragma unroll
   for (int k = 0; k < NCHK; ++k) {
-    const int g = tid + k * NST;
+    const int g = tid + k * TQ;
     const int kind = g / CH, ci = g % CH;
     if (kind < 2) {
       st_src[k] = (kind ? Vh : Kh) + (size_t)ci * 16;
       st_inc[k] = CH * 16;
       st_dst[k] = kind * L::R_BYTES + (ci / RCH_ROW) * L::R_STRIDE + (ci % RCH_ROW) * 16;
-    } else {
+    } else if (kind == 2) {
       st_src[k] = Kth + ((size_t)(ci / TCH_ROW) * d.Np) * EB + (ci % TCH_ROW) * 16;
       st_inc[k] = KT * EB;
       st_dst[k] = 2 * L::R_BYTES + (ci / TCH_ROW) * L::T_STRIDE + (ci % TCH_ROW) * 16;
+    } else {
+      st_src[k] = reinterpret_cast<const char*>(kws + min(ci, KT - 1));
+      st_inc[k] = KT * 16;
+      st_dst[k] = g < NCHUNK ? 2 * L::R_BYTES + L::T_BYTES + ci * 16 : -1;   // past the last chunk: idle
     }
-    if (kt >= 0 || kind > 2) st_dst[k] = -1;   // not a tile thread / past the last chunk
   }
-  const float* st_ka = ka + max(kt, 0);
-  const float* st_kb = kb + max(kt, 0);
 
   auto stage_load = [&](int step) {
 #pragma unroll
@@ -234,19 +269,12 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       if (st_dst[k] >= 0) st[k] = *reinterpret_cast<const u32x4*>(st_src[k]);
       st_src[k] += st_inc[k];
     }
-    if (kt >= 0) { st_a = st_ka[step * KT]; st_b = st_kb[step * KT]; }
   };
   auto stage_store = [&](int buf, int step) {
     char* base = smem + buf * L::BUF;
 #pragma unroll
     for (int k = 0; k < NCHK; ++k)
       if (st_dst[k] >= 0) *reinterpret_cast<u32x4*>(base + st_dst[k]) = st[k];
-    if (kt >= 0) {   // exactly the last wave
-      WinInfo wi;
-      KeyW kw = stage_keys(st_a, st_b, step * KT + kt < d.N, d, jrx_lo, jrx_hi, CAP, wi);
-      *reinterpret_cast<KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES + kt * 16) = kw;
-      if (kt == 0) *reinterpret_cast<WinInfo*>(base + 2 * L::R_BYTES + L::T_BYTES + KT * 16) = wi;
-    }
   };
 
   stage_load(0);
@@ -282,12 +310,15 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
 #ifdef BEVR_PROF
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+  StepBox sb_cur = kbox[0], sb_nxt = kbox[min(1, n_step - 1)];
   for (int step = 0; step < n_step; ++step) {
     PROF_T(t0);
     const int buf = step & 1;
     const char* base = smem + buf * L::BUF;
     if (step + 1 < n_step) stage_load(step + 1);
-    const WinInfo wi = *reinterpret_cast<const WinInfo*>(base + 2 * L::R_BYTES + L::T_BYTES + KT * 16);
+    const WinInfo wi = make_wininfo(sb_cur, jrx_lo, jrx_hi, CAP);   // uniform: scalar loads, one step ahead
+    sb_cur = sb_nxt;
+    sb_nxt = kbox[min(step + 2, n_step - 1)];
     const bool use_win = wi.ok != 0;   // workgroup-uniform
     if (use_win && !region_contains(rg, wi, CAP)) {
       // every wave finished the previous step (barrier at the end of the loop body): safe to drain and move
@@ -316,17 +347,12 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       const KeyW kw = kc[lq];
       const float tx = jrx + (kw.b - (float)rg.ax0);
       const float xf = floorf(tx);
-      ColKeyQ e;
+      CK e;
       const bool dead = step * KT + kh * 32 + lq >= d.N;   // padded key: taps in the kill column => P = 0
       const float fx = tx - xf, fy = kw.fy;
-      e.w00 = dead ? 1.f : (1.0f - fx) * (1.0f - fy);
-      e.w01 = dead ? 0.f : (1.0f - fx) * fy;
-      e.w10 = dead ? 0.f : fx * (1.0f - fy);
-      e.w11 = dead ? 0.f : fx * fy;
+      if (dead) e.set(1.f, 0.f, 0.f, 0.f);
+      else e.set((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy, fx * (1.0f - fy), fx * fy);
       e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (wi.amin - rg.ay0);
-      e.wA = pack_bf16x2(e.w00, e.w01);
-      e.wB = pack_bf16x2(e.w10, e.w11);
-      e.pad = 0;
       pck[lq] = e;
     }
 
@@ -346,8 +372,19 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
       }
-      s = mma_frag(kf, qf, s);       // S^T - LSE
-      dp = mma_frag(vkf, dof, dp);   // dP^T - delta
+      if constexpr (PREC == BEVR_PREC_BF16) {
+        const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 4 * 64 + lane;
+        Frag<PREC> qs, dos;
+        qs.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
+        qs.v[1] = __builtin_bit_cast(bf16x8, qd[64]);
+        dos.v[0] = __builtin_bit_cast(bf16x8, qd[128]);
+        dos.v[1] = __builtin_bit_cast(bf16x8, qd[192]);
+        s = mma_frag(kf, qs, s);        // S^T - LSE
+        dp = mma_frag(vkf, dos, dp);    // dP^T - delta
+      } else {
+        s = mma_frag(kf, qf, s);
+        dp = mma_frag(vkf, dof, dp);
+      }
       PROF_TD(t2, s[0] + dp[15]);
       PROF_ADD(1, t2 - t1);
 
@@ -361,13 +398,13 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
           a = *reinterpret_cast<const tap_t*>(p);
           b = *reinterpret_cast<const tap_t*>(p + WIN_PITCH * ENT);
         };
-        ColKeyQ e0 = pck[crow(0, hi)], e1 = pck[crow(1, hi)];
+        CK e0 = pck[crow(0, hi)], e1 = pck[crow(1, hi)];
         tap_t ta, tb;
         read_tap(e0.cell, ta, tb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           tap_t na = ta, nb = tb;
-          ColKeyQ e2 = e1;
+          CK e2 = e1;
           if (r + 1 < 16) read_tap(e1.cell, na, nb);
           if (r + 2 < 16) e2 = pck[crow(r + 2, hi)];
           float sv;
@@ -377,17 +414,17 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
             sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, tb), __builtin_bit_cast(bf16x2, e0.wB), sv,
                                                  false);
           } else {
-            sv = fmaf(tb[1], e0.w11, fmaf(tb[0], e0.w10, fmaf(ta[1], e0.w01, fmaf(ta[0], e0.w00, s[r]))));
+            sv = fmaf(tb[1], e0.w11(), fmaf(tb[0], e0.w10(), fmaf(ta[1], e0.w01(), fmaf(ta[0], e0.w00(), s[r]))));
           }
           const float ds = fast_exp2(sv) * dp[r];   // padded keys: -1e30 from the kill column => 0
           s[r] = ds;
           // table gradient: four fixed-point adds into the shared window (order-free, so no per-wave windows)
           const float dss = ds * gscale;
           acc_t* g = accw + (e0.cell + lq);
-          atomicAdd(g, Acc::from(dss * e0.w00));
-          atomicAdd(g + 1, Acc::from(dss * e0.w01));
-          atomicAdd(g + WIN_PITCH, Acc::from(dss * e0.w10));
-          atomicAdd(g + WIN_PITCH + 1, Acc::from(dss * e0.w11));
+          atomicAdd(g, Acc::from(dss * e0.w00()));
+          atomicAdd(g + 1, Acc::from(dss * e0.w01()));
+          atomicAdd(g + WIN_PITCH, Acc::from(dss * e0.w10()));
+          atomicAdd(g + WIN_PITCH + 1, Acc::from(dss * e0.w11()));
           e0 = e1; e1 = e2; ta = na; tb = nb;
         }
       } else {
@@ -468,14 +505,14 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
 }
 
 template <int PREC>
-int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt, const void* V, const float* key_a,
-           const float* key_b, const float* table_pair, const void* dO, const float* LSE, const float* delta,
+int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt, const void* V, const void* key_ws,
+           const float* table_pair, const void* dO, const float* LSE, const float* delta,
            const float* grad_scale, float* dQ, float* dtable, hipStream_t st) {
   const int n_rb = d.Sp / 32, n_cb = (d.S + NCOL - 1) / NCOL;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_rb * n_cb;
   hipLaunchKernelGGL((attn_bwd_q_kernel<PREC>), dim3(grid), dim3(TQ), 0, st, d, (const char*)Q, (const char*)K,
-                     (const char*)Kt, (const char*)V, key_a, key_b, (const char*)table_pair, (const char*)dO, LSE,
+                     (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair, (const char*)dO, LSE,
                      delta, grad_scale, dQ, dtable);
   return (int)hipGetLastError();
 }
@@ -483,12 +520,12 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt
 }  // namespace
 
 extern "C" int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
-                               const float* key_a, const float* key_b, const float* table_pair, const void* dO,
+                               const void* key_ws, const float* table_pair, const void* dO,
                                const float* LSE, const float* delta, const float* grad_scale, float* dQ,
                                float* dtable, void* stream) {
   int rc = bevr_check_desc(d);
   if (rc) return rc;
-  if (!Q || !K || !Kt || !V || !key_a || !key_b || !table_pair || !dO || !LSE || !delta || !grad_scale || !dQ ||
+  if (!Q || !K || !Kt || !V || !key_ws || !table_pair || !dO || !LSE || !delta || !grad_scale || !dQ ||
       !dtable)
     return BEVR_E_NULL;
   if (!bevr_aligned16(Q) || !bevr_aligned16(K) || !bevr_aligned16(Kt) || !bevr_aligned16(V) || !bevr_aligned16(dO) ||
@@ -496,7 +533,7 @@ extern "C" int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const voi
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
-    return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_a, key_b, table_pair, dO, LSE, delta, grad_scale, dQ, dtable,
+    return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable,
                                   st);
-  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_a, key_b, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
+  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
 }

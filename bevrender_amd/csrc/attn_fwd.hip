@@ -54,7 +54,7 @@ struct ColKey {
 template <int PREC>
 __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Vt,
-    const float* __restrict__ key_a, const float* __restrict__ key_b, const char* __restrict__ table_pair,
+    const char* __restrict__ key_ws, const char* __restrict__ table_pair,
     float* __restrict__ O, float* __restrict__ LSE) {
   typedef Lds<PREC> L;
   constexpr int EB = L::EB;
@@ -86,8 +86,9 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB;
   const char* Kh = K + ((size_t)ph * d.Np) * 32 * EB;
   const char* Vh = Vt + ((size_t)ph * 32) * d.Np * EB;
-  const float* ka = key_a + (size_t)(prob * d.groups + grp) * d.Np;
-  const float* kb = key_b + (size_t)(prob * d.groups + grp) * d.Np;
+  const int pg = prob * d.groups + grp;
+  const KeyW* kws = reinterpret_cast<const KeyW*>(key_ws) + (size_t)pg * d.Np;
+  const StepBox* kbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / KT);
   const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
   const int Hp8 = d.Hp * 8;
   const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
@@ -114,30 +115,45 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   constexpr int VCH_ROW = KT * EB / 16;            // 16-B chunks per V^T row (this step's keys)
   constexpr int CH = KT * KCH_ROW;                 // chunks per tile: 256 (bf16) / 512 (f32)
   static_assert(CH <= TF && 32 * VCH_ROW == CH, "staging shape");
-  u32x4 stK, stV;
-  float st_a = 0.f, st_b = 0.f;
+  // the 2 CH chunks of the K and V^T tiles are dealt over the TF threads (1 each in bf16 mode, 2 in f32 mode):
+  // per-thread source pointer (advanced by a fixed stride per step) and LDS destination offset
+  constexpr int NCHK = 2 * CH / TF;
+  static_assert(NCHK * TF == 2 * CH, "staging deal");
+  u32x4 st[NCHK];
+  u32x4 st_kw = {0, 0, 0, 0};   // last wave: a key's constants
   const int n_step = d.Np / KT;
+  const char* st_src[NCHK];
+  int st_inc[NCHK], st_dst[NCHK];
+#pragma unroll
+  for (int k = 0; k < NCHK; ++k) {
+    const int g = tid + k * TF;
+    const int kind = g / CH, ci = g % CH;
+    if (kind == 0) {
+      st_src[k] = Kh + (size_t)ci * 16;
+      st_inc[k] = CH * 16;
+      st_dst[k] = (ci / KCH_ROW) * L::K_STRIDE + (ci % KCH_ROW) * 16;
+    } else {
+      st_src[k] = Vh + ((size_t)(ci / VCH_ROW) * d.Np) * EB + (ci % VCH_ROW) * 16;
+      st_inc[k] = KT * EB;
+      st_dst[k] = L::K_BYTES + (ci / VCH_ROW) * L::V_STRIDE + (ci % VCH_ROW) * 16;
+    }
+  }
+  const int kt = tid - (TF - 64);   // key slot of the last wave's lanes: coordinates + bounding box
+  const u32x4* st_kws = reinterpret_cast<const u32x4*>(kws) + max(kt, 0);
 
   auto stage_load = [&](int step) {
-    if (tid < CH) {
-      stK = *reinterpret_cast<const u32x4*>(Kh + ((size_t)step * CH + tid) * 16);
-      int vr = tid / VCH_ROW, vc = tid % VCH_ROW;
-      stV = *reinterpret_cast<const u32x4*>(Vh + ((size_t)vr * d.Np + (size_t)step * KT) * EB + vc * 16);
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) {
+      st[k] = *reinterpret_cast<const u32x4*>(st_src[k]);
+      st_src[k] += st_inc[k];
     }
-    if (tid < KT) { st_a = ka[step * KT + tid]; st_b = kb[step * KT + tid]; }
+    if (kt >= 0) st_kw = st_kws[step * KT];
   };
   auto stage_store = [&](int buf, int step) {
     char* base = smem + buf * L::BUF;
-    if (tid < CH) {
-      *reinterpret_cast<u32x4*>(base + (tid / KCH_ROW) * L::K_STRIDE + (tid % KCH_ROW) * 16) = stK;
-      *reinterpret_cast<u32x4*>(base + L::K_BYTES + (tid / VCH_ROW) * L::V_STRIDE + (tid % VCH_ROW) * 16) = stV;
-    }
-    if (tid < KT) {   // exactly wave 0
-      WinInfo wi;
-      KeyW kw = stage_keys(st_a, st_b, step * KT + tid < d.N, d, jrx_lo, jrx_hi, WIN_COLS, wi);
-      *reinterpret_cast<KeyW*>(base + L::K_BYTES + L::V_BYTES + tid * 16) = kw;
-      if (tid == 0) *reinterpret_cast<WinInfo*>(base + L::K_BYTES + L::V_BYTES + KT * 16) = wi;
-    }
+#pragma unroll
+    for (int k = 0; k < NCHK; ++k) *reinterpret_cast<u32x4*>(base + st_dst[k]) = st[k];
+    if (kt >= 0) *reinterpret_cast<u32x4*>(base + L::K_BYTES + L::V_BYTES + kt * 16) = st_kw;   // the last wave
   };
 
   stage_load(0);
@@ -148,12 +164,15 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   rg.ax0 = -(1 << 28);   // nothing contained: the first windowed step anchors
   rg.ay0 = 0;
 
+  StepBox sb_cur = kbox[0], sb_nxt = kbox[min(1, n_step - 1)];
   for (int step = 0; step < n_step; ++step) {
     const int buf = step & 1;
     const char* base = smem + buf * L::BUF;
     if (step + 1 < n_step) stage_load(step + 1);
     const KeyW* kws = reinterpret_cast<const KeyW*>(base + L::K_BYTES + L::V_BYTES);
-    const WinInfo wi = *reinterpret_cast<const WinInfo*>(base + L::K_BYTES + L::V_BYTES + KT * 16);
+    const WinInfo wi = make_wininfo(sb_cur, jrx_lo, jrx_hi, WIN_COLS);   // uniform: scalar loads, one step ahead
+    sb_cur = sb_nxt;
+    sb_nxt = kbox[min(step + 2, n_step - 1)];
     const bool use_win = wi.ok != 0;   // workgroup-uniform
     if (use_win && !region_contains(rg, wi, WIN_COLS)) {
       rg = region_anchor(wi, d, i0, WIN_COLS);
@@ -287,28 +306,28 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
 }
 
 template <int PREC>
-int launch_fwd(const bevr_attn_desc& d, const void* Q, const void* K, const void* Vt, const float* key_a,
-               const float* key_b, const float* table_pair, float* O, float* LSE, hipStream_t st) {
+int launch_fwd(const bevr_attn_desc& d, const void* Q, const void* K, const void* Vt, const void* key_ws,
+               const float* table_pair, float* O, float* LSE, hipStream_t st) {
   const int n_rb = d.Sp / 32, n_cb = (d.S + NWF - 1) / NWF;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_rb * n_cb;
   hipLaunchKernelGGL((attn_fwd_kernel<PREC>), dim3(grid), dim3(TF), 0, st, d, (const char*)Q, (const char*)K,
-                     (const char*)Vt, key_a, key_b, (const char*)table_pair, O, LSE);
+                     (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O, LSE);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
 extern "C" int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* Vt,
-                             const float* key_a, const float* key_b, const float* table_pair, float* O,
+                             const void* key_ws, const float* table_pair, float* O,
                              float* LSE, void* stream) {
   int rc = bevr_check_desc(d);
   if (rc) return rc;
-  if (!Q || !K || !Vt || !key_a || !key_b || !table_pair || !O || !LSE) return BEVR_E_NULL;
+  if (!Q || !K || !Vt || !key_ws || !table_pair || !O || !LSE) return BEVR_E_NULL;
   if (!bevr_aligned16(Q) || !bevr_aligned16(K) || !bevr_aligned16(Vt) || !bevr_aligned16(O) ||
       !bevr_aligned16(table_pair))
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (d->precision == BEVR_PREC_BF16) return launch_fwd<BEVR_PREC_BF16>(*d, Q, K, Vt, key_a, key_b, table_pair, O, LSE, st);
-  return launch_fwd<BEVR_PREC_F32>(*d, Q, K, Vt, key_a, key_b, table_pair, O, LSE, st);
+  if (d->precision == BEVR_PREC_BF16) return launch_fwd<BEVR_PREC_BF16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
+  return launch_fwd<BEVR_PREC_F32>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
 }

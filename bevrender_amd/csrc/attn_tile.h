@@ -36,54 +36,32 @@ struct WinInfo {
   int pad0, pad1;
 };
 
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = min(v, __shfl_xor(v, s));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = max(v, __shfl_xor(v, s));
-  return v;
-}
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = fminf(v, __shfl_xor(v, s));
-  return v;
-}
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
-  return v;
+// bounding box of a step's live keys, written by the key-preparation kernel (attn_keyprep.hip)
+struct StepBox {
+  int amin, amax;      // min / max floor(a); amax < amin: the step has no live key
+  float bmin, bmax;
+};
+
+// Byte layout of the key workspace handed between bevr_attn_key_prep and the query-stationary kernels:
+//   KeyW   [n_prob * groups][Np]        then
+//   StepBox[n_prob * groups][Np / KT]
+__host__ __device__ __forceinline__ size_t key_ws_box_offset(const bevr_attn_desc& d) {
+  return (size_t)d.n_prob * d.groups * d.Np * sizeof(KeyW);
 }
 
-// Executed by the 64 lanes of wave 0: lane = key within the step.  Returns this key's constants and fills
-// `wi` (identical in all lanes).
-__device__ __forceinline__ KeyW stage_keys(float a, float b, bool live, const bevr_attn_desc& d, float jrx_lo,
-                                           float jrx_hi, int max_cols, WinInfo& wi) {
-  const float aL = -(float)(d.Sp + 1), aU = (float)(d.Ht + 1);
-  const float half = (float)(d.Wt / 2);
-  const float bL = -(half + 2.0f), bU = (float)(d.Wt + 1);
-  a = fminf(fmaxf(a, aL), aU);
-  b = fminf(fmaxf(b, bL), bU);
-  const float af = floorf(a);
-  const int A = (int)af;
-  const int amin = wave_min_i(live ? A : 0x7fffffff), amax = wave_max_i(live ? A : (int)0x80000000);
-  const float bmin = wave_min_f(live ? b : 3.0e38f), bmax = wave_max_f(live ? b : -3.0e38f);
-  wi.amin = amin;
-  wi.nrows = 32 + amax - amin;
-  wi.xlo = (int)floorf(jrx_lo + bmin) - 1;
-  const int xhi = (int)floorf(jrx_hi + bmax) + 2;
+// The table box a (query tile) x (key step) block needs, from the step's key box and the tile's column range.
+// Uniform over the workgroup; every thread evaluates it (a dozen ALU operations per step).
+__device__ __forceinline__ WinInfo make_wininfo(const StepBox& sb, float jrx_lo, float jrx_hi, int max_cols) {
+  WinInfo wi;
+  wi.amin = sb.amin;
+  wi.nrows = 32 + sb.amax - sb.amin;
+  wi.xlo = (int)floorf(jrx_lo + sb.bmin) - 1;
+  const int xhi = (int)floorf(jrx_hi + sb.bmax) + 2;
   wi.ncols = xhi - wi.xlo + 1;
   wi.xlo_f = (float)wi.xlo;
-  wi.ok = (amax >= amin) && (wi.nrows <= WIN_ROWS_MAX) && (wi.ncols <= max_cols);
+  wi.ok = (sb.amax >= sb.amin) && (wi.nrows <= WIN_ROWS_MAX) && (wi.ncols <= max_cols);
   wi.pad0 = wi.pad1 = 0;
-  KeyW k;
-  k.aoff = ((A + d.y_off) + d.x_off * d.Hp) * 8;
-  k.fy = a - af;
-  k.b = live ? b : bmin;   // dead (padded) keys: any in-window column; their logits are masked anyway
-  k.arow8 = live ? (A - amin) * 8 : 0;
-  return k;
+  return wi;
 }
 
 // ---------------------------------------------------------------------------------------------------

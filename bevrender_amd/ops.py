@@ -248,17 +248,21 @@ class _AttnCore(torch.autograd.Function):
         O = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=Qp.device, dtype=torch.float32)
         LSE = torch.empty(geom.n_prob, geom.heads, geom.Mp, device=Qp.device, dtype=torch.float32)
         d = geom.desc()
+        # per-key table coordinates + per-step tap boxes, shared by the forward and the query-side backward
+        key_ws = torch.empty(L.bevr_attn_key_ws_bytes(C.byref(d)), device=Qp.device, dtype=torch.uint8)
+        _lib.check(L.bevr_attn_key_prep(C.byref(d), _ptr(key_a), _ptr(key_b), _ptr(key_ws), _stream()),
+                   "bevr_attn_key_prep")
         _lib.check(KERNEL_TIMER.run("bevr_attn_fwd", _attn_flops(geom, 2), L.bevr_attn_fwd, C.byref(d), _ptr(Qe),
-                                    _ptr(Ke), _ptr(Vt), _ptr(key_a), _ptr(key_b), _ptr(pair), _ptr(O), _ptr(LSE),
+                                    _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O), _ptr(LSE),
                                     _stream()), "bevr_attn_fwd")
         ctx.geom = geom
-        ctx.save_for_backward(Qe, Ke, Ve, key_a, key_b, pair, O, LSE)
+        ctx.save_for_backward(Qe, Ke, Ve, key_a, key_b, pair, O, LSE, key_ws)
         return O
 
     @staticmethod
     def backward(ctx, dO):
         geom: AttnGeom = ctx.geom
-        Qe, Ke, Ve, key_a, key_b, pair, O, LSE = ctx.saved_tensors
+        Qe, Ke, Ve, key_a, key_b, pair, O, LSE, key_ws = ctx.saved_tensors
         L = _lib.lib()
         ed = _edtype(geom.precision)
         dO = dO.contiguous()
@@ -275,7 +279,7 @@ class _AttnCore(torch.autograd.Function):
         e = torch.floor(30.0 - torch.log2(bound.clamp_min(1e-30))).clamp(-100.0, 100.0)
         gscale = torch.stack((torch.exp2(e), torch.exp2(-e))).contiguous()
         _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(geom, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
-                                    _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_a), _ptr(key_b), _ptr(pair), _ptr(dOe),
+                                    _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
                                     _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream()),
                    "bevr_attn_bwd_q")
         del Kt

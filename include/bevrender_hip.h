@@ -25,13 +25,14 @@
 #ifndef BEVRENDER_HIP_H
 #define BEVRENDER_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define BEVR_ABI_VERSION 1
+#define BEVR_ABI_VERSION 2
 
 enum {
   BEVR_OK = 0,
@@ -88,15 +89,23 @@ typedef struct bevr_attn_desc {
 /* Fill Sp, Hp, Wp, y_off, x_off from S, Wt.  Returns 0 or BEVR_E_SHAPE. */
 int bevr_attn_table_dims(bevr_attn_desc* d);
 
+/* Key preparation, once per attention call (shared by bevr_attn_fwd and bevr_attn_bwd_q of the same keys):
+ * clamps key_a/key_b, splits them into table row / fraction / column parts and reduces, per 64-key step, the
+ * bounding box of the table taps the step needs.  key_ws: caller-allocated device buffer of
+ * bevr_attn_key_ws_bytes(d) bytes, 16-byte aligned; its content is opaque to the caller.
+ *   key_a, key_b [n_prob*groups][Np] float */
+size_t bevr_attn_key_ws_bytes(const bevr_attn_desc* d);
+int bevr_attn_key_prep(const bevr_attn_desc* d, const float* key_a, const float* key_b, void* key_ws, void* stream);
+
 /* Forward.  Element type E = float (F32) or bf16 (BF16).
  *   Q   [n_prob/q_div][heads][Mp][32]  E     K  [n_prob][heads][Np][32] E
  *   Vt  [n_prob][heads][32][Np] E, keys permuted inside each aligned block of 32: the key with
  *       in-block index r is stored at position (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1)
  *       (bits 2 and 3 swapped) -- the order the MFMA consumes the P accumulator in.
- *   key_a, key_b [n_prob*groups][Np] float      table_pair as above, float
+ *   key_ws: output of bevr_attn_key_prep for these keys      table_pair as above, float
  *   O   [n_prob][heads][Mp][32] float (normalised)   LSE [n_prob][heads][Mp] float (log2 units) */
 int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* Vt,
-                  const float* key_a, const float* key_b, const float* table_pair,
+                  const void* key_ws, const float* table_pair,
                   float* O, float* LSE, void* stream);
 
 /* Backward, query side (same tiling as the forward):  dQ [like Q, float] and the table gradient
@@ -111,7 +120,7 @@ int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const v
  *   All gradients are with respect to the log2-domain logits' inputs as handed in (Q pre-scaled,
  *   table pre-multiplied): the caller's autograd undoes the scaling. */
 int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
-                    const float* key_a, const float* key_b, const float* table_pair,
+                    const void* key_ws, const float* table_pair,
                     const void* dO, const float* LSE, const float* delta, const float* grad_scale,
                     float* dQ, float* dtable, void* stream);
 

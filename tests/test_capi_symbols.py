@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(L, name), name
     L.bevr_abi_version.restype = ctypes.c_int
-    assert L.bevr_abi_version() == 1
+    assert L.bevr_abi_version() == 2
 
 
 def test_argument_contract_is_checked_without_a_gpu():
@@ -39,9 +39,9 @@ def test_argument_contract_is_checked_without_a_gpu():
     assert L.bevr_attn_table_dims(ctypes.byref(d)) == 0
     assert (d.Sp, d.Ht, d.Hp, d.y_off, d.x_off, d.Wp) == (224, 399, 851, 226, 1003, 4006)
     d.n_prob, d.q_div, d.heads, d.groups, d.N, d.Np, d.precision = 24, 6, 2, 1, 100000, 100032, 1
-    assert L.bevr_attn_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None) == -1
+    assert L.bevr_attn_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None) == -1
     d.Np = 100000                                                    # not a multiple of 64
-    assert L.bevr_attn_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None) == -2
+    assert L.bevr_attn_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None) == -2
     assert L.bevr_sample_fwd(None, None, None, 1, 4, 4, 8, 4, None) == -1
     assert b"contract" in L.bevr_strerror(-2)
 

@@ -39,16 +39,9 @@ template <int PREC> struct Lds {
   static constexpr int C_BYTES = KT * 16 + 32;    // KeyW per key + WinInfo
   static constexpr int BUF = K_BYTES + V_BYTES + C_BYTES;
   static constexpr int WIN = WIN_COLS * WIN_PITCH * ENT;
-  static constexpr int PCK = NWF * KT * 16;       // per-wave (column, key) constants
-  static constexpr int TOTAL = 2 * BUF + WIN + PCK;
-};
-
-// per-(column, key) constants, written by the owning wave once per step (lane = key), read as a broadcast
-struct ColKey {
-  int off;        // byte offset of the tap (column floor(tx), row floor(a)) from the window base
-  float fx;       // frac(tx)
-  float omfx;     // 1 - fx
-  unsigned wy;    // bf16 mode: (1 - fy, fy) packed bf16x2;  f32 mode: bits of fy
+  static constexpr int PCK = NWF * KT * (PREC == BEVR_PREC_BF16 ? 16 : 32);   // per-wave (column, key) constants
+  static constexpr int QL = PREC == BEVR_PREC_BF16 ? NWF * 128 * 16 : 16;       // bf16 mode: Q fragments
+  static constexpr int TOTAL = 2 * BUF + WIN + PCK + QL;
 };
 
 template <int PREC>
@@ -62,7 +55,9 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   constexpr int WIN_COLS = L::WIN_COLS;
   __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
   __shared__ __attribute__((aligned(16))) char win[L::WIN];
-  __shared__ __attribute__((aligned(16))) ColKey pck_all[NWF * KT];
+  typedef ColKeyT<PREC> CK;
+  __shared__ __attribute__((aligned(16))) CK pck_all[NWF * KT];
+  __shared__ __attribute__((aligned(16))) char qlds[L::QL];
 
   // ---- which (problem, head, query tile) -------------------------------------------------------
   const int n_rb = d.Sp / 32;
@@ -79,7 +74,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   const int qb = prob / d.q_div;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
-  ColKey* pck = pck_all + wave * KT;
+  CK* pck = pck_all + wave * KT;
   const int Mp = d.S * d.Sp;
   const int i0 = rb * 32;
 
@@ -102,6 +97,11 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   const float jrx = (float)jc * rx;
   Frag<PREC> qf;
   qf.load(Qh + ((size_t)jc * d.Sp + i0 + lq) * 32 * EB, hi);
+  if constexpr (PREC == BEVR_PREC_BF16) {   // bf16 mode: the Q fragment lives in LDS (re-read per tile), not in 8 registers
+    u32x4* ql = reinterpret_cast<u32x4*>(qlds) + wave * 128 + lane;
+    ql[0] = __builtin_bit_cast(u32x4, qf.v[0]);
+    ql[64] = __builtin_bit_cast(u32x4, qf.v[1]);
+  }
   const int rowoff = (i0 + lq) * 8;
   const int lqe = lq * ENT;
 
@@ -122,32 +122,35 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   u32x4 st[NCHK];
   u32x4 st_kw = {0, 0, 0, 0};   // last wave: a key's constants
   const int n_step = d.Np / KT;
-  const char* st_src[NCHK];
+  // a chunk's tile (K or V^T) is uniform over its wave: uniform base pointer + 32-bit per-thread byte offset
+  const char* st_base[NCHK];
+  unsigned st_off[NCHK];
   int st_inc[NCHK], st_dst[NCHK];
 #pragma unroll
   for (int k = 0; k < NCHK; ++k) {
     const int g = tid + k * TF;
-    const int kind = g / CH, ci = g % CH;
+    const int kind = __builtin_amdgcn_readfirstlane(g / CH), ci = g % CH;
+    st_base[k] = kind ? Vh : Kh;
+    st_inc[k] = kind ? KT * EB : CH * 16;
     if (kind == 0) {
-      st_src[k] = Kh + (size_t)ci * 16;
-      st_inc[k] = CH * 16;
+      st_off[k] = (unsigned)ci * 16;
       st_dst[k] = (ci / KCH_ROW) * L::K_STRIDE + (ci % KCH_ROW) * 16;
     } else {
-      st_src[k] = Vh + ((size_t)(ci / VCH_ROW) * d.Np) * EB + (ci % VCH_ROW) * 16;
-      st_inc[k] = KT * EB;
+      st_off[k] = (unsigned)(((size_t)(ci / VCH_ROW) * d.Np) * EB + (ci % VCH_ROW) * 16);
       st_dst[k] = L::K_BYTES + (ci / VCH_ROW) * L::V_STRIDE + (ci % VCH_ROW) * 16;
     }
   }
-  const int kt = tid - (TF - 64);   // key slot of the last wave's lanes: coordinates + bounding box
-  const u32x4* st_kws = reinterpret_cast<const u32x4*>(kws) + max(kt, 0);
+  const int kt = tid - (TF - 64);   // key slot of the last wave's lanes
 
   auto stage_load = [&](int step) {
 #pragma unroll
-    for (int k = 0; k < NCHK; ++k) {
-      st[k] = *reinterpret_cast<const u32x4*>(st_src[k]);
-      st_src[k] += st_inc[k];
+    for (int k = 0; k < NCHK; ++k)
+      st[k] = *reinterpret_cast<const u32x4*>(st_base[k] + (size_t)step * st_inc[k] + st_off[k]);
+    if (kt >= 0) {   // uniform base + laundered lane offset: no per-thread 64-bit pointer to keep alive (or spill)
+      int ko = kt * 16;
+      asm volatile("" : "+v"(ko));
+      st_kw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(kws + (size_t)step * KT) + ko);
     }
-    if (kt >= 0) st_kw = st_kws[step * KT];
   };
   auto stage_store = [&](int buf, int step) {
     char* base = smem + buf * L::BUF;
@@ -192,12 +195,10 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       const KeyW kw = kws[lane];
       const float tx = jrx + (kw.b - (float)rg.ax0);
       const float xf = floorf(tx);
-      ColKey e;
-      e.fx = tx - xf;
-      e.omfx = 1.0f - e.fx;
-      e.off = (int)xf * (WIN_PITCH * ENT) + ((kw.arow8 >> 3) + (wi.amin - rg.ay0)) * ENT;
-      if constexpr (PREC == BEVR_PREC_BF16) e.wy = pack_bf16x2(1.0f - kw.fy, kw.fy);
-      else e.wy = __builtin_bit_cast(unsigned, kw.fy);
+      CK e;
+      const float fx = tx - xf, fy = kw.fy;
+      e.set((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy, fx * (1.0f - fy), fx * fy);
+      e.cell = (int)xf * (WIN_PITCH * ENT) + ((kw.arow8 >> 3) + (wi.amin - rg.ay0)) * ENT;
       pck[lane] = e;   // read back by this wave only: LDS operations of a wave execute in order
     }
 
@@ -210,29 +211,32 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = -m;
-      s = mma_frag(kf, qf, s);   // S^T - m
+      if constexpr (PREC == BEVR_PREC_BF16) {   // own lanes' data, written by this wave: no barrier needed
+        const u32x4* ql = reinterpret_cast<const u32x4*>(qlds) + wave * 128 + lane;
+        Frag<PREC> qs;
+        qs.v[0] = __builtin_bit_cast(bf16x8, ql[0]);
+        qs.v[1] = __builtin_bit_cast(bf16x8, ql[64]);
+        s = mma_frag(kf, qs, s);   // S^T - m
+      } else {
+        s = mma_frag(kf, qf, s);
+      }
 
       // relative-position bias: rows of the tile are keys crow(r, hi); lanes are BEV rows i0 + lq.
       if (use_win) {
         const char* wl = win + lqe;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const ColKey e = pck[ks * 32 + crow(r, hi)];
-          const char* p = wl + e.off;
+          const CK e = pck[ks * 32 + crow(r, hi)];
+          const char* p = wl + e.cell;
           if constexpr (PREC == BEVR_PREC_BF16) {
             const bf16x2 t0 = __builtin_bit_cast(bf16x2, *reinterpret_cast<const unsigned*>(p));
             const bf16x2 t1 = __builtin_bit_cast(bf16x2, *reinterpret_cast<const unsigned*>(p + WIN_PITCH * ENT));
-            const bf16x2 wy = __builtin_bit_cast(bf16x2, e.wy);
-            const float u0 = __builtin_amdgcn_fdot2_f32_bf16(t0, wy, 0.f, false);
-            const float u1 = __builtin_amdgcn_fdot2_f32_bf16(t1, wy, 0.f, false);
-            s[r] = fmaf(u1, e.fx, fmaf(u0, e.omfx, s[r]));
+            float sv = __builtin_amdgcn_fdot2_f32_bf16(t0, __builtin_bit_cast(bf16x2, e.wA), s[r], false);
+            s[r] = __builtin_amdgcn_fdot2_f32_bf16(t1, __builtin_bit_cast(bf16x2, e.wB), sv, false);
           } else {
             const f32x2 t0 = *reinterpret_cast<const f32x2*>(p);
             const f32x2 t1 = *reinterpret_cast<const f32x2*>(p + WIN_PITCH * ENT);
-            const float fy = __builtin_bit_cast(float, e.wy), wy0 = 1.0f - fy;
-            const float u0 = t0[0] * wy0 + t0[1] * fy;
-            const float u1 = t1[0] * wy0 + t1[1] * fy;
-            s[r] = fmaf(u1, e.fx, fmaf(u0, e.omfx, s[r]));
+            s[r] = fmaf(t1[1], e.w11(), fmaf(t1[0], e.w10(), fmaf(t0[1], e.w01(), fmaf(t0[0], e.w00(), s[r]))));
           }
         }
       } else {

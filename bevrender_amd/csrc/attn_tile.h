@@ -64,6 +64,40 @@ __device__ __forceinline__ WinInfo make_wininfo(const StepBox& sb, float jrx_lo,
   return wi;
 }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// per-(column, key) constants, written by the owning wave once per step (lane = key), read as a broadcast.
+// bf16 mode keeps only the packed bf16 tap weights (the gradient unpacks them: the weights the bias was computed
+// with); f32 mode keeps them in full precision.
+template <int PREC> struct ColKeyT;
+template <> struct ColKeyT<BEVR_PREC_BF16> {
+  int cell;         // first tap's window position for lane row 0: cell index (backward) or byte offset (forward)
+  unsigned wA, wB;  // tap weights of column x / x + 1 as packed bf16x2 (row y, row y + 1)
+  unsigned pad;
+  __device__ __forceinline__ void set(float w00, float w01, float w10, float w11) {
+    wA = pack_bf16x2(w00, w01);
+    wB = pack_bf16x2(w10, w11);
+    pad = 0;
+  }
+  __device__ __forceinline__ float w00() const { return __builtin_bit_cast(float, wA << 16); }
+  __device__ __forceinline__ float w01() const { return __builtin_bit_cast(float, wA & 0xffff0000u); }
+  __device__ __forceinline__ float w10() const { return __builtin_bit_cast(float, wB << 16); }
+  __device__ __forceinline__ float w11() const { return __builtin_bit_cast(float, wB & 0xffff0000u); }
+};
+template <> struct ColKeyT<BEVR_PREC_F32> {
+  int cell;
+  unsigned pad0, pad1, pad2;
+  float f00, f01, f10, f11;   // (1-fx)(1-fy), (1-fx)fy, fx(1-fy), fx fy
+  __device__ __forceinline__ void set(float w00, float w01, float w10, float w11) {
+    f00 = w00; f01 = w01; f10 = w10; f11 = w11;
+    pad0 = pad1 = pad2 = 0;
+  }
+  __device__ __forceinline__ float w00() const { return f00; }
+  __device__ __forceinline__ float w01() const { return f01; }
+  __device__ __forceinline__ float w10() const { return f10; }
+  __device__ __forceinline__ float w11() const { return f11; }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // Persistent window ("region"): a fixed-capacity box of the table, WIN_PITCH rows x NCOL columns, anchored
 // at table coordinates (ax0, ay0) relative to this workgroup's first BEV row.  A step whose bounding box

@@ -1,5 +1,5 @@
 // Attention backward, key side: dK, dV and the gradients of the keys' table coordinates (a_n, b_n).
-// Key-stationary: a workgroup owns 4 waves x KW x 32 keys and sweeps all query tiles, so every per-key sum
+// Key-stationary: a workgroup owns 256 consecutive keys and sweeps all query tiles, so every per-key sum
 // stays in registers and nothing is reduced across workgroups.  Orientation here is "key on the lane":
 // tiles are S[query][key], which makes P and dS the B operands of
 //   dV^T[c][key] += dO^T[c][q] P[q][key]      dK^T[c][key] += Q^T[c][q] dS[q][key]
@@ -7,22 +7,163 @@
 // tile are 16 consecutive-ish BEV rows of one column, so the bilinear taps are reached with immediate
 // offsets from one per-lane base address.
 // Row constants (-LSE[q], -delta[q]) are preloaded into the accumulators of S and dP.
+//
+// Two kernels cover the key blocks between them (each exits at once on the other's blocks):
+//  * attn_bwd_k_win_kernel: 8 waves x 32 keys, 4 waves per SIMD.  The sweep runs column-major over the BEV
+//    grid, so for one BEV column j the block's 256 keys touch the table only in
+//      rows    [Amin, Amax + Sp]                    (all 32-row tiles of the column)
+//      columns [floor(j rx + bmin), floor(j rx + bmax) + 1]
+//    That slab is kept in LDS as a ring of table columns (f32, one value per entry): moving to column j + 1
+//    shifts the range right by rx, so only ~rx new table columns are fetched per BEV column.  Taps are then
+//    LDS reads at immediate offsets from two per-lane bases.
+//  * attn_bwd_k_gather_kernel: the general path (4 waves x 64 keys, taps gathered from L2) for blocks whose
+//    slab does not fit the ring (keys of the block far apart in table space).
 #include "bevr_common.h"
 
 namespace {
 
-constexpr int THREADS = 256;
-constexpr int QT = 32;  // queries per iteration (one 32-row block of one BEV column)
+constexpr int QT = 32;          // queries per iteration (one 32-row block of one BEV column)
+constexpr int KEYS_WIN = 512;   // keys per workgroup of the window kernel: the unit of ownership
+constexpr int KEYS_G = 256;     // keys per workgroup of the gather kernel (half a unit)
+
+// bounding box of a key block in table coordinates (padded keys excluded)
+struct KBox { int amin, amax; float bmin, bmax; };
+
+__device__ __forceinline__ int wred_min_i(int v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = min(v, __shfl_xor(v, s));
+  return v;
+}
+__device__ __forceinline__ int wred_max_i(int v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = max(v, __shfl_xor(v, s));
+  return v;
+}
+__device__ __forceinline__ float wred_min_f(float v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = fminf(v, __shfl_xor(v, s));
+  return v;
+}
+__device__ __forceinline__ float wred_max_f(float v) {
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+  return v;
+}
+
+// Workgroup-wide box from per-lane partial boxes (empty: lo > hi).  red: n_wave KBox slots in LDS.  Ends with a
+// barrier; the result is uniform.
+__device__ __forceinline__ KBox wg_key_box(int a_lo, int a_hi, float b_lo, float b_hi, KBox* red, int n_wave, int wave,
+                                           int lane) {
+  KBox w;
+  w.amin = wred_min_i(a_lo);
+  w.amax = wred_max_i(a_hi);
+  w.bmin = wred_min_f(b_lo);
+  w.bmax = wred_max_f(b_hi);
+  if (lane == 0) red[wave] = w;
+  __syncthreads();
+  KBox r = red[0];
+  for (int k = 1; k < n_wave; ++k) {
+    const KBox o = red[k];
+    r.amin = min(r.amin, o.amin);
+    r.amax = max(r.amax, o.amax);
+    r.bmin = fminf(r.bmin, o.bmin);
+    r.bmax = fmaxf(r.bmax, o.bmax);
+  }
+  return r;
+}
+
+// Ring geometry of a block's table slab; `fits` decides which kernel owns the block.
+struct Slab {
+  int rows;     // Amax - Amin + Sp + 1: window row w is padded table row Amin + y_off + w
+  int pitch;    // rows | 1 (odd: spreads the lanes' columns over the banks)
+  int ncw;      // ring capacity in table columns
+  bool fits;
+};
+__device__ __forceinline__ Slab make_slab(const KBox& kb, const bevr_attn_desc& d, int wcap) {
+  Slab sl;
+  if (kb.amax < kb.amin) {   // no live key in the block: nothing to compute; the window kernel owns it
+    sl.rows = 1; sl.pitch = 1; sl.ncw = 1; sl.fits = true;
+    return sl;
+  }
+  sl.rows = kb.amax - kb.amin + d.Sp + 1;
+  sl.pitch = sl.rows | 1;
+  sl.ncw = wcap / sl.pitch;
+  const int need = (int)floorf(kb.bmax - kb.bmin) + 4;   // columns of one BEV column's range, plus slack
+  sl.fits = sl.ncw >= need;
+  return sl;
+}
+
+// clamp a key's table coordinates exactly as make_keyc does and split off the integer row
+__device__ __forceinline__ void key_split(float a, float b, const bevr_attn_desc& d, int& A, float& fy, float& bc) {
+  const float aL = -(float)(d.Sp + 1), aU = (float)(d.Ht + 1);
+  const float half = (float)((d.Wt) / 2);
+  const float bL = -(half + 2.0f), bU = (float)(d.Wt + 1);
+  a = fminf(fmaxf(a, aL), aU);
+  bc = fminf(fmaxf(b, bL), bU);
+  const float af = floorf(a);
+  A = (int)af;
+  fy = a - af;
+}
 
 template <int PREC> struct LdsK {
   static constexpr int EB = Elem<PREC>::bytes;
   static constexpr int STRIDE = 32 * EB + 16;  // every tile is 32 rows x 32 elements
   static constexpr int TILE = 32 * STRIDE;
   static constexpr int BUF = 4 * TILE + 2 * QT * 4;  // Q, dO, Qt, dOt, lse, delta
+  static constexpr int WCAP = PREC == BEVR_PREC_BF16 ? 30720 : 26624;   // ring capacity, f32 entries (one workgroup per CU)
 };
 
-template <int PREC, int KW>
-__global__ __launch_bounds__(THREADS) void attn_bwd_k_kernel(
+// ---- query-tile staging shared by both kernels ----------------------------------------------------------
+template <int PREC, int THREADS> struct QStage {
+  typedef LdsK<PREC> L;
+  static constexpr int EB = L::EB;
+  static constexpr int CHR = 32 * EB / 16;            // 16-B chunks per 32-element row
+  static constexpr int CH_ARR = 32 * CHR;             // chunks per tile (128 / 256)
+  static constexpr int NCH = 4 * CH_ARR / THREADS;    // chunks per thread
+  static_assert(NCH * THREADS == 4 * CH_ARR, "staging deal");
+  u32x4 st[NCH];
+  float st_c;
+  const char* base[NCH];    // array base pointer (uniform per chunk slot: the array index is wave-uniform)
+  unsigned off[NCH];        // per-thread byte offset inside the array for tile 0
+  int mul[NCH];             // bytes per query index step
+  int dst[NCH];
+  const float* cbase;       // wave 0: LSE row constants, wave 1: delta (lanes < 32 each)
+
+  __device__ __forceinline__ void init(int tid, const char* Qh, const char* dOh, const char* Qth, const char* dOth,
+                                       const float* LSEh, const float* dlth, int Mp) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int cid = tid + c * THREADS;
+      const int arr = __builtin_amdgcn_readfirstlane(cid / CH_ARR), a = cid % CH_ARR;
+      const int row = a / CHR, cc = a % CHR;
+      base[c] = arr == 0 ? Qh : arr == 1 ? dOh : arr == 2 ? Qth : dOth;
+      if (arr < 2) { off[c] = (unsigned)a * 16; mul[c] = 32 * EB; }
+      else { off[c] = (unsigned)(((size_t)row * Mp) * EB + cc * 16); mul[c] = EB; }
+      dst[c] = arr * L::TILE + row * L::STRIDE + cc * 16;
+    }
+    st_c = 0.f;
+    cbase = (tid >> 6) == 0 ? LSEh : dlth;
+  }
+  __device__ __forceinline__ void load(int tid, size_t mq0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) st[c] = *reinterpret_cast<const u32x4*>(base[c] + mq0 * mul[c] + off[c]);
+    if (tid < 128 && (tid & 63) < QT) st_c = cbase[mq0 + (tid & 63)];
+  }
+  __device__ __forceinline__ void store(int tid, char* buf) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<u32x4*>(buf + dst[c]) = st[c];
+    if (tid < 128 && (tid & 63) < QT) *reinterpret_cast<float*>(buf + 4 * L::TILE + ((tid >> 6) * QT + (tid & 63)) * 4) = st_c;
+  }
+};
+
+// =========================================================================================================
+// Window kernel
+// =========================================================================================================
+constexpr int TW = 512;   // 8 waves x KWW x 32 keys, 2 waves per SIMD (256 registers): one workgroup per CU
+constexpr int KWW = 2;
+
+template <int PREC>
+__global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ Qt, const char* __restrict__ K,
     const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const char* __restrict__ dOt,
@@ -30,10 +171,11 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_k_kernel(
     float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
   typedef LdsK<PREC> L;
   constexpr int EB = L::EB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
+  __shared__ __attribute__((aligned(16))) float win[L::WCAP];
+  __shared__ __attribute__((aligned(16))) KBox red[8];
 
-  const int keys_wg = 4 * KW * 32;
-  const int n_kb = (d.Np + keys_wg - 1) / keys_wg;
+  const int n_kb = (d.Np + KEYS_WIN - 1) / KEYS_WIN;
   const int n_ph = d.n_prob * d.heads;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int ph = (slot / n_kb) * 8 + xcd;
@@ -47,12 +189,257 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_k_kernel(
   const int Mp = d.S * d.Sp;
   const int n_rb = d.Sp / 32;
 
-  const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB;
-  const char* Qth = Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB;
-  const char* dOh = dO + ((size_t)ph * Mp) * 32 * EB;
-  const char* dOth = dOt + ((size_t)ph * 32) * Mp * EB;
-  const float* LSEh = LSE + (size_t)ph * Mp;
-  const float* dlth = delta + (size_t)ph * Mp;
+  const char* Kh = K + ((size_t)ph * d.Np) * 32 * EB;
+  const char* Vh = V + ((size_t)ph * d.Np) * 32 * EB;
+  const float* ka = key_a + (size_t)(prob * d.groups + grp) * d.Np;
+  const float* kb = key_b + (size_t)(prob * d.groups + grp) * d.Np;
+  const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
+  const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
+
+  // ---- this wave's KWW x 32 keys ---------------------------------------------------------------------
+  bool wave_live[KWW], dead[KWW];
+  int key[KWW], A[KWW];
+  float fy[KWW], bcl[KWW];
+  int a_lo = 0x7fffffff, a_hi = (int)0x80000000;
+  float b_lo = 3.0e38f, b_hi = -3.0e38f;
+#pragma unroll
+  for (int w = 0; w < KWW; ++w) {
+    const int k0 = kblk * KEYS_WIN + (wave * KWW + w) * 32;
+    wave_live[w] = k0 < d.Np;                       // wave-uniform
+    key[w] = wave_live[w] ? k0 + lq : lq;           // dead sub-tiles read a valid address, never store
+    dead[w] = !wave_live[w] || key[w] >= d.N;       // padded key: P = 0
+    key_split(ka[key[w]], kb[key[w]], d, A[w], fy[w], bcl[w]);
+    if (!dead[w]) {
+      a_lo = min(a_lo, A[w]); a_hi = max(a_hi, A[w]);
+      b_lo = fminf(b_lo, bcl[w]); b_hi = fmaxf(b_hi, bcl[w]);
+    }
+  }
+  const KBox box = wg_key_box(a_lo, a_hi, b_lo, b_hi, red, TW / 64, wave, lane);
+  const Slab sl = make_slab(box, d, L::WCAP);
+  if (!sl.fits) return;                  // the gather kernel owns this block (uniform exit)
+  if (box.amax < box.amin) {             // only padded keys: their gradients are zero
+#pragma unroll
+    for (int w = 0; w < KWW; ++w) {
+      if (!wave_live[w]) continue;
+      float* kr = dK + ((size_t)ph * d.Np + key[w]) * 32;
+      float* vr = dV + ((size_t)ph * d.Np + key[w]) * 32;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        *reinterpret_cast<f32x4*>(kr + 8 * g4 + 4 * hi) = z;
+        *reinterpret_cast<f32x4*>(vr + 8 * g4 + 4 * hi) = z;
+      }
+    }
+    return;
+  }
+  float wy0[KWW];
+  int arel4[KWW];
+  Frag<PREC> kf[KWW], vf[KWW];
+  f32x16 dk[KWW], dv[KWW];
+  float da[KWW], db[KWW], fx[KWW];
+  int base0[KWW], base1[KWW];   // byte offsets of the lane's taps (row i = 0) in ring columns X and X + 1
+#pragma unroll
+  for (int w = 0; w < KWW; ++w) {
+    if (dead[w]) { A[w] = box.amin; bcl[w] = box.bmin; fy[w] = 0.f; }   // any in-window tap
+    wy0[w] = 1.0f - fy[w];
+    arel4[w] = (A[w] - box.amin) * 4;                   // byte offset of the key's row 0 inside a ring column
+    kf[w].load(Kh + (size_t)key[w] * 32 * EB, hi);
+    vf[w].load(Vh + (size_t)key[w] * 32 * EB, hi);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[w][r] = 0.f; dv[w][r] = 0.f; }
+    da[w] = 0.f; db[w] = 0.f; fx[w] = 0.f; base0[w] = 0; base1[w] = 0;
+  }
+
+  QStage<PREC, TW> qs;
+  qs.init(tid, Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB, dO + ((size_t)ph * Mp) * 32 * EB,
+          Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB, dOt + ((size_t)ph * 32) * Mp * EB,
+          LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp);
+  const int n_it = d.S * n_rb;
+  qs.load(tid, 0);
+  qs.store(tid, smem);
+
+  // ring state (uniform): table columns [wlo, whi] are resident; column X lives in slot (X - xbase) % ncw
+  const int xbase = (int)floorf(box.bmin) - 8;
+  const float inv_ncw = 1.0f / (float)sl.ncw;
+  auto slot_of = [&](int X) {   // X >= xbase always
+    const int xs = X - xbase;
+    int q = (int)((float)xs * inv_ncw);
+    int r = xs - q * sl.ncw;
+    r = r < 0 ? r + sl.ncw : r;
+    r = r >= sl.ncw ? r - sl.ncw : r;
+    return r;
+  };
+  int whi = -(1 << 30);
+  const int n_chunk = (sl.rows + 63) / 64;
+  const size_t trow0 = (size_t)(box.amin + d.y_off);
+  __syncthreads();
+
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+    const char* base = smem + buf * L::BUF;
+    const int j = it / n_rb, rb = it - j * n_rb;
+    if (it + 1 < n_it) {
+      const int jn = (it + 1) / n_rb, rbn = (it + 1) - jn * n_rb;
+      qs.load(tid, (size_t)jn * d.Sp + rbn * 32);
+    }
+    if (rb == 0) {
+      // ---- new BEV column: slide the ring and refresh the lanes' tap bases -------------------------
+      const float jr = (float)j * rx;
+      const int xlo = (int)floorf(jr + box.bmin), xhi = (int)floorf(jr + box.bmax) + 1;
+      const int xfirst = max(whi + 1, xlo);
+      const int n_new = xhi - xfirst + 1;
+      for (int u = wave; u < n_new * n_chunk; u += TW / 64) {   // uniform trip count per wave
+        const int c = u / n_chunk, ch = u - c * n_chunk;
+        const int X = xfirst + c;
+        const int row = ch * 64 + lane;
+        if (row < sl.rows) {
+          const float v = *reinterpret_cast<const float*>(tbl + ((size_t)(X + d.x_off) * d.Hp + trow0 + row) * 8);
+          win[slot_of(X) * sl.pitch + row] = v;
+        }
+      }
+      whi = xhi;
+#pragma unroll
+      for (int w = 0; w < KWW; ++w) {
+        const float tx = jr + bcl[w];
+        const float xf = floorf(tx);
+        fx[w] = tx - xf;
+        const int X = (int)xf;
+        base0[w] = slot_of(X) * sl.pitch * 4 + arel4[w];
+        base1[w] = slot_of(X + 1) * sl.pitch * 4 + arel4[w];
+      }
+      __syncthreads();
+    }
+
+#pragma unroll
+    for (int w = 0; w < KWW; ++w) {
+      if (!wave_live[w]) continue;
+      const f32x4* rc = reinterpret_cast<const f32x4*>(base + 4 * L::TILE);
+      f32x16 s, dp;
+      // one operand fragment alive at a time (the register budget is 128): S first, then dP
+      {
+        Frag<PREC> qf;
+        qf.load(base + lq * L::STRIDE, hi);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {   // rows 8 g4 + 4 hi + 0..3
+          const f32x4 l4 = rc[2 * g4 + hi];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s[4 * g4 + k] = -l4[k];
+        }
+        s = mma_frag(qf, kf[w], s);      // S[q][key] - LSE[q]
+      }
+      {
+        Frag<PREC> dof;
+        dof.load(base + L::TILE + lq * L::STRIDE, hi);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 d4 = rc[8 + 2 * g4 + hi];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dp[4 * g4 + k] = -d4[k];
+        }
+        dp = mma_frag(dof, vf[w], dp);   // dP[q][key] - delta[q]
+      }
+
+      const int ioff = (rb * 32 + 4 * hi) * 4;
+      const char* p0 = reinterpret_cast<const char*>(win) + base0[w] + ioff;
+      const char* p1 = reinterpret_cast<const char*>(win) + base1[w] + ioff;
+      float sa = 0.f, sb = 0.f;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float c0[5], c1[5];   // five consecutive table rows of columns X and X + 1
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          c0[k] = *reinterpret_cast<const float*>(p0 + (8 * g4 + k) * 4);
+          c1[k] = *reinterpret_cast<const float*>(p1 + (8 * g4 + k) * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = 4 * g4 + k;
+          const float u0 = c0[k] * wy0[w] + c0[k + 1] * fy[w];
+          const float u1 = c1[k] * wy0[w] + c1[k + 1] * fy[w];
+          const float du = u1 - u0;
+          const float sv = s[r] + u0 + fx[w] * du;
+          const float p = dead[w] ? 0.f : fast_exp2(sv);
+          const float ds = p * dp[r];   // ln2 folded into the epilogue
+          s[r] = p;
+          dp[r] = ds;
+          const float d0 = c0[k + 1] - c0[k], d1 = c1[k + 1] - c1[k];
+          sa += ds * (d0 + fx[w] * (d1 - d0));   // d bias / d a
+          sb += ds * du;                      // d bias / d b
+        }
+      }
+      da[w] += sa;
+      db[w] += sb;
+      {
+        Frag<PREC> dotf;
+        load_perm(dotf, base + 3 * L::TILE + lq * L::STRIDE, hi);
+        dv[w] = mma_acc_b(dotf, s, dv[w]);
+      }
+      {
+        Frag<PREC> qtf;
+        load_perm(qtf, base + 2 * L::TILE + lq * L::STRIDE, hi);
+        dk[w] = mma_acc_b(qtf, dp, dk[w]);
+      }
+    }
+
+    if (it + 1 < n_it) qs.store(tid, smem + (buf ^ 1) * L::BUF);
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------
+#pragma unroll
+  for (int w = 0; w < KWW; ++w) {
+    if (!wave_live[w]) continue;
+    float* kr = dK + ((size_t)ph * d.Np + key[w]) * 32;
+    float* vr = dV + ((size_t)ph * d.Np + key[w]) * 32;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 a, b;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a[k] = BEVR_LN2 * dk[w][4 * g4 + k]; b[k] = dv[w][4 * g4 + k]; }
+      *reinterpret_cast<f32x4*>(kr + 8 * g4 + 4 * hi) = a;
+      *reinterpret_cast<f32x4*>(vr + 8 * g4 + 4 * hi) = b;
+    }
+    const float sa = BEVR_LN2 * (da[w] + __shfl_xor(da[w], 32));
+    const float sb = BEVR_LN2 * (db[w] + __shfl_xor(db[w], 32));
+    if (hi == 0) {
+      atomicAdd(dkey_a + (size_t)(prob * d.groups + grp) * d.Np + key[w], sa);
+      atomicAdd(dkey_b + (size_t)(prob * d.groups + grp) * d.Np + key[w], sb);
+    }
+  }
+}
+
+// =========================================================================================================
+// Gather kernel (general path)
+// =========================================================================================================
+constexpr int TG = 256;   // 4 waves x 2 x 32 keys: half an ownership unit
+constexpr int KW = 2;
+
+template <int PREC>
+__global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
+    bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ Qt, const char* __restrict__ K,
+    const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
+    const char* __restrict__ table_pair, const char* __restrict__ dO, const char* __restrict__ dOt,
+    const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV,
+    float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
+  typedef LdsK<PREC> L;
+  constexpr int EB = L::EB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
+  __shared__ __attribute__((aligned(16))) KBox red[4];
+
+  const int n_kb = 2 * ((d.Np + KEYS_WIN - 1) / KEYS_WIN);
+  const int n_ph = d.n_prob * d.heads;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ph = (slot / n_kb) * 8 + xcd;
+  if (ph >= n_ph) return;
+  const int kblk = slot % n_kb;
+  const int prob = ph / d.heads, hd = ph % d.heads;
+  const int grp = hd / (d.heads / d.groups);
+  const int qb = prob / d.q_div;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
+  const int Mp = d.S * d.Sp;
+  const int n_rb = d.Sp / 32;
+
   const char* Kh = K + ((size_t)ph * d.Np) * 32 * EB;
   const char* Vh = V + ((size_t)ph * d.Np) * 32 * EB;
   const float* ka = key_a + (size_t)(prob * d.groups + grp) * d.Np;
@@ -62,19 +449,42 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_k_kernel(
   const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
 
   // ---- this wave's keys: operands and table coordinates stay in registers for the whole sweep -------
-  Frag<PREC> kf[KW], vf[KW];
   KeyC kc[KW];
   bool wave_live[KW];
   int key_idx[KW];
 #pragma unroll
   for (int w = 0; w < KW; ++w) {
-    const int k0 = kblk * keys_wg + (wave * KW + w) * 32;
+    const int k0 = kblk * KEYS_G + (wave * KW + w) * 32;
     wave_live[w] = k0 < d.Np;                       // wave-uniform
     const int key = wave_live[w] ? k0 + lq : lq;    // dead sub-tiles read a valid address, never store
     key_idx[w] = key;
-    kf[w].load(Kh + (size_t)key * 32 * EB, hi);
-    vf[w].load(Vh + (size_t)key * 32 * EB, hi);
     kc[w] = make_keyc(ka[key], kb[key], d);
+  }
+  KBox box;
+  {
+    // the unit's box decides the owner: the same reduction over the same 512 keys as the window kernel
+    int a_lo = 0x7fffffff, a_hi = (int)0x80000000;
+    float b_lo = 3.0e38f, b_hi = -3.0e38f;
+#pragma unroll
+    for (int w = 0; w < KEYS_WIN / TG; ++w) {
+      const int k = (kblk >> 1) * KEYS_WIN + w * TG + tid;
+      if (k < d.N) {
+        int A;
+        float fy, bc;
+        key_split(ka[k], kb[k], d, A, fy, bc);
+        a_lo = min(a_lo, A); a_hi = max(a_hi, A);
+        b_lo = fminf(b_lo, bc); b_hi = fmaxf(b_hi, bc);
+      }
+    }
+    box = wg_key_box(a_lo, a_hi, b_lo, b_hi, red, TG / 64, wave, lane);
+  }
+  if (make_slab(box, d, L::WCAP).fits) return;   // the window kernel owns this block (uniform exit)
+
+  Frag<PREC> kf[KW], vf[KW];
+#pragma unroll
+  for (int w = 0; w < KW; ++w) {
+    kf[w].load(Kh + (size_t)key_idx[w] * 32 * EB, hi);
+    vf[w].load(Vh + (size_t)key_idx[w] * 32 * EB, hi);
   }
   f32x16 dk[KW], dv[KW];
   float da[KW], db[KW];
@@ -86,52 +496,23 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_k_kernel(
     db[w] = 0.f;
   }
 
-  // ---- staging of one query tile: Q, dO rows; Qt, dOt transposed+permuted; lse, delta --------------
-  constexpr int CHR = 32 * EB / 16;        // 16-B chunks per 32-element row
-  constexpr int CH_ARR = 32 * CHR;         // chunks per tile (128 / 256)
-  constexpr int NCH = 4 * CH_ARR / THREADS;  // 2 / 4
-  u32x4 st[NCH];
-  float st_c = 0.f;
+  QStage<PREC, TG> qs;
+  qs.init(tid, Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB, dO + ((size_t)ph * Mp) * 32 * EB,
+          Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB, dOt + ((size_t)ph * 32) * Mp * EB,
+          LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp);
   const int n_it = d.S * n_rb;
-
-  auto stage_load = [&](int it) {
-    const int j = it / n_rb, rb = it % n_rb;
-    const size_t mq0 = (size_t)j * d.Sp + rb * 32;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int cid = tid + c * THREADS;
-      const int arr = cid / CH_ARR, a = cid % CH_ARR;   // arr is wave-uniform
-      const int row = a / CHR, cc = a % CHR;
-      const char* src;
-      if (arr == 0) src = Qh + (mq0 * 32) * EB + (size_t)a * 16;
-      else if (arr == 1) src = dOh + (mq0 * 32) * EB + (size_t)a * 16;
-      else if (arr == 2) src = Qth + ((size_t)row * Mp + mq0) * EB + cc * 16;
-      else src = dOth + ((size_t)row * Mp + mq0) * EB + cc * 16;
-      st[c] = *reinterpret_cast<const u32x4*>(src);
-    }
-    if (tid < QT) st_c = LSEh[mq0 + tid];
-    else if (tid < 2 * QT) st_c = dlth[mq0 + tid - QT];
-  };
-  auto stage_store = [&](int buf) {
-    char* base = smem + buf * L::BUF;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int cid = tid + c * THREADS;
-      const int arr = cid / CH_ARR, a = cid % CH_ARR;
-      *reinterpret_cast<u32x4*>(base + arr * L::TILE + (a / CHR) * L::STRIDE + (a % CHR) * 16) = st[c];
-    }
-    if (tid < 2 * QT) *reinterpret_cast<float*>(base + 4 * L::TILE + tid * 4) = st_c;
-  };
-
-  stage_load(0);
-  stage_store(0);
+  qs.load(tid, 0);
+  qs.store(tid, smem);
   __syncthreads();
 
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
     const char* base = smem + buf * L::BUF;
-    if (it + 1 < n_it) stage_load(it + 1);
     const int j = it / n_rb, i0 = (it % n_rb) * 32;
+    if (it + 1 < n_it) {
+      const int jn = (it + 1) / n_rb, rbn = (it + 1) % n_rb;
+      qs.load(tid, (size_t)jn * d.Sp + rbn * 32);
+    }
     const float jr = (float)j * rx;
 
     Frag<PREC> qf, dof, qtf, dotf;
@@ -182,7 +563,7 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_k_kernel(
       dk[w] = mma_acc_b(qtf, dp, dk[w]);
     }
 
-    if (it + 1 < n_it) stage_store(buf ^ 1);
+    if (it + 1 < n_it) qs.store(tid, smem + (buf ^ 1) * L::BUF);
     __syncthreads();
   }
 
@@ -210,16 +591,19 @@ __global__ __launch_bounds__(THREADS) void attn_bwd_k_kernel(
   }
 }
 
-template <int PREC, int KW>
+template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K, const void* V, const float* key_a,
            const float* key_b, const float* table_pair, const void* dO, const void* dOt, const float* LSE,
            const float* delta, float* dK, float* dV, float* dka, float* dkb, hipStream_t st) {
-  const int keys_wg = 4 * KW * 32;
-  const int n_kb = (d.Np + keys_wg - 1) / keys_wg;
+  const int n_kb = (d.Np + KEYS_WIN - 1) / KEYS_WIN;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_kb;
-  const size_t lds = 2 * LdsK<PREC>::BUF;
-  hipLaunchKernelGGL((attn_bwd_k_kernel<PREC, KW>), dim3(grid), dim3(THREADS), lds, st, d, (const char*)Q,
+  hipLaunchKernelGGL((attn_bwd_k_win_kernel<PREC>), dim3(grid), dim3(TW), 0, st, d, (const char*)Q, (const char*)Qt,
+                     (const char*)K, (const char*)V, key_a, key_b, (const char*)table_pair, (const char*)dO,
+                     (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_bwd_k_gather_kernel<PREC>), dim3(2 * grid), dim3(TG), 0, st, d, (const char*)Q,
                      (const char*)Qt, (const char*)K, (const char*)V, key_a, key_b, (const char*)table_pair,
                      (const char*)dO, (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
   return (int)hipGetLastError();
@@ -241,8 +625,8 @@ extern "C" int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const voi
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
-    return launch<BEVR_PREC_BF16, 2>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, dK, dV, dkey_a,
-                                     dkey_b, st);
-  return launch<BEVR_PREC_F32, 1>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, dK, dV, dkey_a,
+    return launch<BEVR_PREC_BF16>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, dK, dV, dkey_a,
                                   dkey_b, st);
+  return launch<BEVR_PREC_F32>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, dK, dV, dkey_a, dkey_b,
+                               st);
 }

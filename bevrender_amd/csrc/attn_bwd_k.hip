@@ -20,11 +20,28 @@
 //    slab does not fit the ring (keys of the block far apart in table space).
 #include "bevr_common.h"
 
+#ifdef BEVR_PROF
+__device__ unsigned long long bevr_prof_k[16];
+extern "C" int bevr_debug_prof_k(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(bevr_prof_k), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bevr_prof_k), 16 * 8);
+}
+__device__ __forceinline__ unsigned long long prof_now(float dep) {
+  unsigned long long t;
+  asm volatile("s_nop 0\n s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  return t;
+}
+#define PROF_TD(var, dep) const unsigned long long var = prof_now(dep)
+#define PROF_ADD(i, v) pacc[i] += (v)
+#else
+#define PROF_TD(var, dep)
+#define PROF_ADD(i, v)
+#endif
+
 namespace {
 
 constexpr int QT = 32;          // queries per iteration (one 32-row block of one BEV column)
-constexpr int KEYS_WIN = 512;   // keys per workgroup of the window kernel: the unit of ownership
-constexpr int KEYS_G = 256;     // keys per workgroup of the gather kernel (half a unit)
+constexpr int KEYS_WG = 384;    // keys per workgroup, both kernels: the unit of ownership
 
 // bounding box of a key block in table coordinates (padded keys excluded)
 struct KBox { int amin, amax; float bmin, bmax; };
@@ -79,7 +96,7 @@ struct Slab {
   int ncw;      // ring capacity in table columns
   bool fits;
 };
-__device__ __forceinline__ Slab make_slab(const KBox& kb, const bevr_attn_desc& d, int wcap) {
+__device__ __forceinline__ Slab make_slab(const KBox& kb, const bevr_attn_desc& d, int wcap, float rx_ceil) {
   Slab sl;
   if (kb.amax < kb.amin) {   // no live key in the block: nothing to compute; the window kernel owns it
     sl.rows = 1; sl.pitch = 1; sl.ncw = 1; sl.fits = true;
@@ -87,8 +104,9 @@ __device__ __forceinline__ Slab make_slab(const KBox& kb, const bevr_attn_desc& 
   }
   sl.rows = kb.amax - kb.amin + d.Sp + 1;
   sl.pitch = sl.rows | 1;
-  sl.ncw = wcap / sl.pitch;
-  const int need = (int)floorf(kb.bmax - kb.bmin) + 4;   // columns of one BEV column's range, plus slack
+  sl.ncw = wcap / sl.pitch - 1;   // the last column of the LDS array is the "kill" column of padded keys
+  // columns of one BEV column's range plus those of the next (prefetched while this one is in use), plus slack
+  const int need = (int)floorf(kb.bmax - kb.bmin) + 4 + (int)rx_ceil + 1;
   sl.fits = sl.ncw >= need;
   return sl;
 }
@@ -119,8 +137,7 @@ template <int PREC, int THREADS> struct QStage {
   static constexpr int EB = L::EB;
   static constexpr int CHR = 32 * EB / 16;            // 16-B chunks per 32-element row
   static constexpr int CH_ARR = 32 * CHR;             // chunks per tile (128 / 256)
-  static constexpr int NCH = 4 * CH_ARR / THREADS;    // chunks per thread
-  static_assert(NCH * THREADS == 4 * CH_ARR, "staging deal");
+  static constexpr int NCH = (4 * CH_ARR + THREADS - 1) / THREADS;    // chunks per thread (the last slot may be partial)
   u32x4 st[NCH];
   float st_c;
   const char* base[NCH];    // array base pointer (uniform per chunk slot: the array index is wave-uniform)
@@ -136,22 +153,24 @@ template <int PREC, int THREADS> struct QStage {
       const int cid = tid + c * THREADS;
       const int arr = __builtin_amdgcn_readfirstlane(cid / CH_ARR), a = cid % CH_ARR;
       const int row = a / CHR, cc = a % CHR;
-      base[c] = arr == 0 ? Qh : arr == 1 ? dOh : arr == 2 ? Qth : dOth;
-      if (arr < 2) { off[c] = (unsigned)a * 16; mul[c] = 32 * EB; }
+      base[c] = arr == 0 ? Qh : arr == 1 ? dOh : arr == 2 ? Qth : dOth;   // arr >= 4: idle slot (dst < 0)
+      if (arr < 2 || arr >= 4) { off[c] = (unsigned)a * 16; mul[c] = 32 * EB; }
       else { off[c] = (unsigned)(((size_t)row * Mp) * EB + cc * 16); mul[c] = EB; }
-      dst[c] = arr * L::TILE + row * L::STRIDE + cc * 16;
+      dst[c] = cid < 4 * CH_ARR ? arr * L::TILE + row * L::STRIDE + cc * 16 : -1;
     }
     st_c = 0.f;
     cbase = (tid >> 6) == 0 ? LSEh : dlth;
   }
   __device__ __forceinline__ void load(int tid, size_t mq0) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) st[c] = *reinterpret_cast<const u32x4*>(base[c] + mq0 * mul[c] + off[c]);
-    if (tid < 128 && (tid & 63) < QT) st_c = cbase[mq0 + (tid & 63)];
+    for (int c = 0; c < NCH; ++c)
+      if (dst[c] >= 0) st[c] = *reinterpret_cast<const u32x4*>(base[c] + mq0 * mul[c] + off[c]);
+    if (tid < 128 && (tid & 63) < QT) st_c = -cbase[mq0 + (tid & 63)];   // negated: they seed the accumulators
   }
   __device__ __forceinline__ void store(int tid, char* buf) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) *reinterpret_cast<u32x4*>(buf + dst[c]) = st[c];
+    for (int c = 0; c < NCH; ++c)
+      if (dst[c] >= 0) *reinterpret_cast<u32x4*>(buf + dst[c]) = st[c];
     if (tid < 128 && (tid & 63) < QT) *reinterpret_cast<float*>(buf + 4 * L::TILE + ((tid >> 6) * QT + (tid & 63)) * 4) = st_c;
   }
 };
@@ -159,11 +178,11 @@ template <int PREC, int THREADS> struct QStage {
 // =========================================================================================================
 // Window kernel
 // =========================================================================================================
-constexpr int TW = 512;   // 8 waves x KWW x 32 keys, 2 waves per SIMD (256 registers): one workgroup per CU
-constexpr int KWW = 2;
+constexpr int TW = 768;   // 12 waves x 32 keys, 3 waves per SIMD (170 registers): one workgroup per CU
+constexpr int KWW = 1;
 
 template <int PREC>
-__global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
+__global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ Qt, const char* __restrict__ K,
     const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const char* __restrict__ dOt,
@@ -173,9 +192,9 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
   constexpr int EB = L::EB;
   __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
   __shared__ __attribute__((aligned(16))) float win[L::WCAP];
-  __shared__ __attribute__((aligned(16))) KBox red[8];
+  __shared__ __attribute__((aligned(16))) KBox red[TW / 64];
 
-  const int n_kb = (d.Np + KEYS_WIN - 1) / KEYS_WIN;
+  const int n_kb = (d.Np + KEYS_WG - 1) / KEYS_WG;
   const int n_ph = d.n_prob * d.heads;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int ph = (slot / n_kb) * 8 + xcd;
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
   float b_lo = 3.0e38f, b_hi = -3.0e38f;
 #pragma unroll
   for (int w = 0; w < KWW; ++w) {
-    const int k0 = kblk * KEYS_WIN + (wave * KWW + w) * 32;
+    const int k0 = kblk * KEYS_WG + (wave * KWW + w) * 32;
     wave_live[w] = k0 < d.Np;                       // wave-uniform
     key[w] = wave_live[w] ? k0 + lq : lq;           // dead sub-tiles read a valid address, never store
     dead[w] = !wave_live[w] || key[w] >= d.N;       // padded key: P = 0
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
     }
   }
   const KBox box = wg_key_box(a_lo, a_hi, b_lo, b_hi, red, TW / 64, wave, lane);
-  const Slab sl = make_slab(box, d, L::WCAP);
+  const Slab sl = make_slab(box, d, L::WCAP, ceilf(rx));
   if (!sl.fits) return;                  // the gather kernel owns this block (uniform exit)
   if (box.amax < box.amin) {             // only padded keys: their gradients are zero
 #pragma unroll
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
   int base0[KWW], base1[KWW];   // byte offsets of the lane's taps (row i = 0) in ring columns X and X + 1
 #pragma unroll
   for (int w = 0; w < KWW; ++w) {
-    if (dead[w]) { A[w] = box.amin; bcl[w] = box.bmin; fy[w] = 0.f; }   // any in-window tap
+    if (dead[w]) { A[w] = box.amin; bcl[w] = box.bmin; fy[w] = 0.f; }   // padded key: taps in the kill column => P = 0
     wy0[w] = 1.0f - fy[w];
     arel4[w] = (A[w] - box.amin) * 4;                   // byte offset of the key's row 0 inside a ring column
     kf[w].load(Kh + (size_t)key[w] * 32 * EB, hi);
@@ -270,11 +289,18 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
     return r;
   };
   int whi = -(1 << 30);
+  constexpr int PF = 4;   // prefetch registers per lane: up to PF * 12 (column, 64-row chunk) units per BEV column
+  const int kill_off = sl.ncw * sl.pitch * 4;   // byte offset of the kill column: -1e30 everywhere
+  for (int r = tid; r < sl.pitch; r += TW) win[sl.ncw * sl.pitch + r] = BEVR_NEG_BIG;
   const int n_chunk = (sl.rows + 63) / 64;
   const size_t trow0 = (size_t)(box.amin + d.y_off);
   __syncthreads();
 
+#ifdef BEVR_PROF
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int it = 0; it < n_it; ++it) {
+    PROF_TD(t0, 0.f);
     const int buf = it & 1;
     const char* base = smem + buf * L::BUF;
     const int j = it / n_rb, rb = it - j * n_rb;
@@ -283,32 +309,61 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
       qs.load(tid, (size_t)jn * d.Sp + rbn * 32);
     }
     if (rb == 0) {
-      // ---- new BEV column: slide the ring and refresh the lanes' tap bases -------------------------
+      // ---- new BEV column: make its table columns resident and refresh the lanes' tap bases -----------
       const float jr = (float)j * rx;
-      const int xlo = (int)floorf(jr + box.bmin), xhi = (int)floorf(jr + box.bmax) + 1;
-      const int xfirst = max(whi + 1, xlo);
-      const int n_new = xhi - xfirst + 1;
-      for (int u = wave; u < n_new * n_chunk; u += TW / 64) {   // uniform trip count per wave
-        const int c = u / n_chunk, ch = u - c * n_chunk;
-        const int X = xfirst + c;
-        const int row = ch * 64 + lane;
-        if (row < sl.rows) {
-          const float v = *reinterpret_cast<const float*>(tbl + ((size_t)(X + d.x_off) * d.Hp + trow0 + row) * 8);
-          win[slot_of(X) * sl.pitch + row] = v;
+      const int xhi = (int)floorf(jr + box.bmax) + 1;
+      if (whi < xhi) {   // not prefetched (first column, or a shift too large for the prefetch registers)
+        const int xlo = (int)floorf(jr + box.bmin);
+        const int xfirst = max(whi + 1, xlo);
+        const int n_new = xhi - xfirst + 1;
+        for (int u = wave; u < n_new * n_chunk; u += TW / 64) {   // uniform trip count per wave
+          const int c = u / n_chunk, ch = u - c * n_chunk;
+          const int X = xfirst + c;
+          const int row = ch * 64 + lane;
+          if (row < sl.rows) {
+            const float v = *reinterpret_cast<const float*>(tbl + ((size_t)(X + d.x_off) * d.Hp + trow0 + row) * 8);
+            win[slot_of(X) * sl.pitch + row] = v;
+          }
         }
+        whi = xhi;
+        __syncthreads();
       }
-      whi = xhi;
 #pragma unroll
       for (int w = 0; w < KWW; ++w) {
         const float tx = jr + bcl[w];
         const float xf = floorf(tx);
-        fx[w] = tx - xf;
+        fx[w] = dead[w] ? 0.f : tx - xf;
         const int X = (int)xf;
-        base0[w] = slot_of(X) * sl.pitch * 4 + arel4[w];
-        base1[w] = slot_of(X + 1) * sl.pitch * 4 + arel4[w];
+        base0[w] = dead[w] ? kill_off : slot_of(X) * sl.pitch * 4 + arel4[w];
+        base1[w] = dead[w] ? kill_off : slot_of(X + 1) * sl.pitch * 4 + arel4[w];
       }
-      __syncthreads();
     }
+    // prefetch of the next BEV column's new table columns: loads now, LDS stores before this iteration's barrier
+    // (their slots are outside the current column's range: make_slab reserved the room)
+    int pf_first = 0, pf_units = 0;
+    float pf_v[PF];
+    if (rb == n_rb - 1 && j + 1 < d.S) {
+      const float jr = (float)(j + 1) * rx;
+      const int xhi = (int)floorf(jr + box.bmax) + 1;
+      const int xfirst = max(whi + 1, (int)floorf(jr + box.bmin));
+      const int units = (xhi - xfirst + 1) * n_chunk;
+      if (units <= PF * (TW / 64)) {
+        pf_first = xfirst;
+        pf_units = units;
+        whi = xhi;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+          const int u = wave + k * (TW / 64);
+          const int c = u / n_chunk, ch = u - c * n_chunk;
+          const int row = ch * 64 + lane;
+          pf_v[k] = 0.f;
+          if (u < units && row < sl.rows)
+            pf_v[k] = *reinterpret_cast<const float*>(tbl + ((size_t)(xfirst + c + d.x_off) * d.Hp + trow0 + row) * 8);
+        }
+      }
+    }
+    PROF_TD(t1, 0.f);
+    PROF_ADD(0, t1 - t0);
 
 #pragma unroll
     for (int w = 0; w < KWW; ++w) {
@@ -323,7 +378,7 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
         for (int g4 = 0; g4 < 4; ++g4) {   // rows 8 g4 + 4 hi + 0..3
           const f32x4 l4 = rc[2 * g4 + hi];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) s[4 * g4 + k] = -l4[k];
+          for (int k = 0; k < 4; ++k) s[4 * g4 + k] = l4[k];
         }
         s = mma_frag(qf, kf[w], s);      // S[q][key] - LSE[q]
       }
@@ -334,41 +389,48 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
         for (int g4 = 0; g4 < 4; ++g4) {
           const f32x4 d4 = rc[8 + 2 * g4 + hi];
 #pragma unroll
-          for (int k = 0; k < 4; ++k) dp[4 * g4 + k] = -d4[k];
+          for (int k = 0; k < 4; ++k) dp[4 * g4 + k] = d4[k];
         }
         dp = mma_frag(dof, vf[w], dp);   // dP[q][key] - delta[q]
       }
+      PROF_TD(t2, s[0] + dp[15]);
+      PROF_ADD(1, t2 - t1);
 
       const int ioff = (rb * 32 + 4 * hi) * 4;
       const char* p0 = reinterpret_cast<const char*>(win) + base0[w] + ioff;
       const char* p1 = reinterpret_cast<const char*>(win) + base1[w] + ioff;
-      float sa = 0.f, sb = 0.f;
+      // two query rows per instruction (v_pk_*_f32): rows (k, k + 1) of a group are registers (r, r + 1), and
+      // the taps are read as aligned register pairs (rows k, k+1) and (rows k+1, k+2)
+      const f32x2 wy2 = {wy0[w], wy0[w]}, fy2 = {fy[w], fy[w]}, fx2 = {fx[w], fx[w]};
+      f32x2 sa2 = {0.f, 0.f}, sb2 = {0.f, 0.f};
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        float c0[5], c1[5];   // five consecutive table rows of columns X and X + 1
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          c0[k] = *reinterpret_cast<const float*>(p0 + (8 * g4 + k) * 4);
-          c1[k] = *reinterpret_cast<const float*>(p1 + (8 * g4 + k) * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = 4 * g4 + k;
-          const float u0 = c0[k] * wy0[w] + c0[k + 1] * fy[w];
-          const float u1 = c1[k] * wy0[w] + c1[k + 1] * fy[w];
-          const float du = u1 - u0;
-          const float sv = s[r] + u0 + fx[w] * du;
-          const float p = dead[w] ? 0.f : fast_exp2(sv);
-          const float ds = p * dp[r];   // ln2 folded into the epilogue
-          s[r] = p;
-          dp[r] = ds;
-          const float d0 = c0[k + 1] - c0[k], d1 = c1[k + 1] - c1[k];
-          sa += ds * (d0 + fx[w] * (d1 - d0));   // d bias / d a
-          sb += ds * du;                      // d bias / d b
+        for (int h = 0; h < 2; ++h) {
+          const int r = 4 * g4 + 2 * h, o = (8 * g4 + 2 * h) * 4;
+          const float* a0 = reinterpret_cast<const float*>(p0 + o);
+          const float* a1 = reinterpret_cast<const float*>(p1 + o);
+          const f32x2 ta = {a0[0], a0[1]}, tb = {a0[1], a0[2]};   // column X:     rows (k, k+1), (k+1, k+2)
+          const f32x2 qa = {a1[0], a1[1]}, qb = {a1[1], a1[2]};   // column X + 1
+          const f32x2 u0 = ta * wy2 + tb * fy2;
+          const f32x2 u1 = qa * wy2 + qb * fy2;
+          const f32x2 du = u1 - u0;
+          const f32x2 s2 = {s[r], s[r + 1]}, dp2 = {dp[r], dp[r + 1]};
+          const f32x2 sv = (s2 + u0) + fx2 * du;
+          const f32x2 pp = {fast_exp2(sv[0]), fast_exp2(sv[1])};   // padded keys: -1e30 from the kill column => 0
+          const f32x2 ds = pp * dp2;                               // ln2 folded into the epilogue
+          s[r] = pp[0]; s[r + 1] = pp[1];
+          dp[r] = ds[0]; dp[r + 1] = ds[1];
+          const f32x2 d0 = tb - ta, d1 = qb - qa;
+          sa2 += ds * (d0 + fx2 * (d1 - d0));   // d bias / d a
+          sb2 += ds * du;                       // d bias / d b
         }
       }
+      const float sa = sa2[0] + sa2[1], sb = sb2[0] + sb2[1];
       da[w] += sa;
       db[w] += sb;
+      PROF_TD(t3, sa + sb + s[15]);
+      PROF_ADD(2, t3 - t2);
       {
         Frag<PREC> dotf;
         load_perm(dotf, base + 3 * L::TILE + lq * L::STRIDE, hi);
@@ -379,11 +441,34 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
         load_perm(qtf, base + 2 * L::TILE + lq * L::STRIDE, hi);
         dk[w] = mma_acc_b(qtf, dp, dk[w]);
       }
+      PROF_TD(t4, dk[w][0] + dv[w][0]);
+      PROF_ADD(3, t4 - t3);
     }
 
+    PROF_TD(t5, 0.f);
+    if (pf_units > 0) {
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int u = wave + k * (TW / 64);
+        const int c = u / n_chunk, ch = u - c * n_chunk;
+        const int row = ch * 64 + lane;
+        if (u < pf_units && row < sl.rows) win[slot_of(pf_first + c) * sl.pitch + row] = pf_v[k];
+      }
+    }
     if (it + 1 < n_it) qs.store(tid, smem + (buf ^ 1) * L::BUF);
+    PROF_TD(t6, 0.f);
     __syncthreads();
+    PROF_TD(t7, 0.f);
+    PROF_ADD(4, t6 - t5);
+    PROF_ADD(5, t7 - t6);
+    PROF_ADD(6, t7 - t0);
+    PROF_ADD(7, 1);
   }
+#ifdef BEVR_PROF
+  if (lane == 0 && (wave == 0 || wave == 11)) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof_k[(wave ? 8 : 0) + i], pacc[i]);
+  }
+#endif
 
   // ---- epilogue -------------------------------------------------------------------------------------
 #pragma unroll
@@ -411,8 +496,8 @@ __global__ __launch_bounds__(TW, 2) void attn_bwd_k_win_kernel(
 // =========================================================================================================
 // Gather kernel (general path)
 // =========================================================================================================
-constexpr int TG = 256;   // 4 waves x 2 x 32 keys: half an ownership unit
-constexpr int KW = 2;
+constexpr int TG = 256;   // 4 waves x 3 x 32 keys
+constexpr int KW = 3;
 
 template <int PREC>
 __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
@@ -426,7 +511,7 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
   __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
   __shared__ __attribute__((aligned(16))) KBox red[4];
 
-  const int n_kb = 2 * ((d.Np + KEYS_WIN - 1) / KEYS_WIN);
+  const int n_kb = (d.Np + KEYS_WG - 1) / KEYS_WG;
   const int n_ph = d.n_prob * d.heads;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int ph = (slot / n_kb) * 8 + xcd;
@@ -454,7 +539,7 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
   int key_idx[KW];
 #pragma unroll
   for (int w = 0; w < KW; ++w) {
-    const int k0 = kblk * KEYS_G + (wave * KW + w) * 32;
+    const int k0 = kblk * KEYS_WG + (wave * KW + w) * 32;
     wave_live[w] = k0 < d.Np;                       // wave-uniform
     const int key = wave_live[w] ? k0 + lq : lq;    // dead sub-tiles read a valid address, never store
     key_idx[w] = key;
@@ -462,23 +547,22 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
   }
   KBox box;
   {
-    // the unit's box decides the owner: the same reduction over the same 512 keys as the window kernel
+    // the unit's box decides the owner: the same reduction over the same keys as the window kernel
     int a_lo = 0x7fffffff, a_hi = (int)0x80000000;
     float b_lo = 3.0e38f, b_hi = -3.0e38f;
 #pragma unroll
-    for (int w = 0; w < KEYS_WIN / TG; ++w) {
-      const int k = (kblk >> 1) * KEYS_WIN + w * TG + tid;
-      if (k < d.N) {
+    for (int w = 0; w < KW; ++w) {
+      if (wave_live[w] && key_idx[w] < d.N) {
         int A;
         float fy, bc;
-        key_split(ka[k], kb[k], d, A, fy, bc);
+        key_split(ka[key_idx[w]], kb[key_idx[w]], d, A, fy, bc);
         a_lo = min(a_lo, A); a_hi = max(a_hi, A);
         b_lo = fminf(b_lo, bc); b_hi = fmaxf(b_hi, bc);
       }
     }
     box = wg_key_box(a_lo, a_hi, b_lo, b_hi, red, TG / 64, wave, lane);
   }
-  if (make_slab(box, d, L::WCAP).fits) return;   // the window kernel owns this block (uniform exit)
+  if (make_slab(box, d, L::WCAP, ceilf(rx)).fits) return;   // the window kernel owns this block (uniform exit)
 
   Frag<PREC> kf[KW], vf[KW];
 #pragma unroll
@@ -530,7 +614,7 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
       for (int g4 = 0; g4 < 4; ++g4) {   // rows 8 g4 + 4 hi + 0..3
         f32x4 l4 = rc[2 * g4 + hi], d4 = rc[8 + 2 * g4 + hi];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s[4 * g4 + k] = -l4[k]; dp[4 * g4 + k] = -d4[k]; }
+        for (int k = 0; k < 4; ++k) { s[4 * g4 + k] = l4[k]; dp[4 * g4 + k] = d4[k]; }
       }
       s = mma_frag(qf, kf[w], s);      // S[q][key] - LSE[q]
       dp = mma_frag(dof, vf[w], dp);   // dP[q][key] - delta[q]
@@ -595,7 +679,7 @@ template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K, const void* V, const float* key_a,
            const float* key_b, const float* table_pair, const void* dO, const void* dOt, const float* LSE,
            const float* delta, float* dK, float* dV, float* dka, float* dkb, hipStream_t st) {
-  const int n_kb = (d.Np + KEYS_WIN - 1) / KEYS_WIN;
+  const int n_kb = (d.Np + KEYS_WG - 1) / KEYS_WG;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_kb;
   hipLaunchKernelGGL((attn_bwd_k_win_kernel<PREC>), dim3(grid), dim3(TW), 0, st, d, (const char*)Q, (const char*)Qt,
@@ -603,7 +687,7 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K
                      (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_k_gather_kernel<PREC>), dim3(2 * grid), dim3(TG), 0, st, d, (const char*)Q,
+  hipLaunchKernelGGL((attn_bwd_k_gather_kernel<PREC>), dim3(grid), dim3(TG), 0, st, d, (const char*)Q,
                      (const char*)Qt, (const char*)K, (const char*)V, key_a, key_b, (const char*)table_pair,
                      (const char*)dO, (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
   return (int)hipGetLastError();

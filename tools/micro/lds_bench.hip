@@ -23,6 +23,11 @@ __global__ __launch_bounds__(1024) void k(int iters, unsigned* out, int stride) 
       else if (MODE == 3) { a[j] = it; asm volatile("" ::: "memory"); }
       else if (MODE == 4) { acc += a[j]; asm volatile("" ::: "memory"); }
       else if (MODE == 5) { acc += (unsigned)b[j]; asm volatile("" ::: "memory"); }
+      else if (MODE == 7) { const uint4 v = *reinterpret_cast<const uint4*>(&a[((idx >> 6) * 4 + u * 8 + (lane >> 5) * 16) & 16380]); acc += v.x + v.w; asm volatile("" ::: "memory"); }
+      else if (MODE == 8) { const uint4 v = *reinterpret_cast<const uint4*>(&a[(j * 4) & 16380]); acc += v.x + v.w; asm volatile("" ::: "memory"); }
+      else if (MODE == 9) { acc += a[((idx >> 6) + u * 8 + (lane >> 5) * 16) & 16383]; asm volatile("" ::: "memory"); }
+      else if (MODE == 10) { const int q = (j * 2) & 8190; acc += (unsigned)b[q] + (unsigned)b[q + 1]; asm volatile("" ::: "memory"); }
+      else if (MODE == 11) { typedef unsigned long long u64x2 __attribute__((ext_vector_type(2))); u64x2 v; const int q = ((j * 2) & 8190) * 8 + 65536; asm volatile("ds_read2_b64 %0, %1 offset1:1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(q) : "memory"); acc += (unsigned)v.x + (unsigned)v.y; }
       else if (MODE == 6) { unsigned v = it; asm volatile("ds_add_u32 %0, %1" :: "v"(j * 4), "v"(v) : "memory"); }
     }
   }
@@ -53,6 +58,11 @@ int main() {
     run<3>("store b32", stride);
     run<4>("load b32", stride);
     run<5>("load b64", stride);
+    run<7>("load b128 broadcast(2 addr)", stride);
+    run<8>("load b128 per-lane", stride);
+    run<9>("load b32 broadcast(2 addr)", stride);
+    run<10>("load 2 x b64 (compiler)", stride);
+    run<11>("ds_read2_b64 asm", stride);
   }
   return 0;
 }

@@ -89,7 +89,9 @@ typedef struct bevr_attn_desc {
 /* Fill Sp, Hp, Wp, y_off, x_off from S, Wt.  Returns 0 or BEVR_E_SHAPE. */
 int bevr_attn_table_dims(bevr_attn_desc* d);
 
-/* Key preparation, once per attention call (shared by bevr_attn_fwd and bevr_attn_bwd_q of the same keys):
+/* Key preparation, once per attention call (shared by bevr_attn_fwd and bevr_attn_bwd_q of the same keys);
+ * replaces the query-grid / key-position displacement of model/SCA_deform_attn.py:352-378 and
+ * model/TSA_deform_attn.py:264-291 (reference), reduced to per-key table coordinates:
  * clamps key_a/key_b, splits them into table row / fraction / column parts and reduces, per 64-key step, the
  * bounding box of the table taps the step needs.  key_ws: caller-allocated device buffer of
  * bevr_attn_key_ws_bytes(d) bytes, 16-byte aligned; its content is opaque to the caller.

@@ -14,9 +14,11 @@
 //     The fixed-point unit is 2^-30 (f32 mode) / 2^-26 (bf16 mode) of a bound on |dS| handed in by the caller
 //     (grad_scale); see AccCell.
 //     Steps whose box does not fit scatter straight to global memory with float atomics.
-// Workgroup = 16 waves (4 per SIMD, <= 128 registers each) on one 32-row x 8-column query tile: wave w owns
-// column (w & 7) and the key half (w >> 3) of every 64-key step; the two key halves' dQ partial sums are merged
-// through LDS at the end.
+// Workgroup = 8 waves on one 32-row x 8-column query tile (wave = column; both 32-key halves of a 64-key step in
+// turn), TWO workgroups per CU (4 waves per SIMD, <= 128 registers): the kernel's phases -- staging, MFMA, the
+// LDS-issue-bound bias/gradient loop, region moves -- are separated by barriers inside a workgroup, so a second
+// resident workgroup is what keeps the LDS pipe busy during the other's non-LDS phases.  One staging buffer
+// (registers decouple the global loads) keeps a workgroup under 80 KB of LDS.
 // Recomputes S from Q, K and the bias instead of storing any (M x N) tensor.
 // Gradient semantics: see include/bevrender_hip.h (log2-domain inputs as handed in).
 #include <type_traits>
@@ -44,9 +46,9 @@ __device__ __forceinline__ unsigned long long prof_now(float dep) {
 
 namespace {
 
-constexpr int TQ = 1024;  // threads per workgroup
+constexpr int TQ = 512;   // threads per workgroup
 constexpr int NWAVE = TQ / 64;
-constexpr int NCOL = 8;   // query columns per workgroup (one per wave of a key half)
+constexpr int NCOL = 8;   // query columns per workgroup (one per wave)
 
 template <int PREC> struct LdsQ {
   static constexpr int EB = Elem<PREC>::bytes;
@@ -61,11 +63,11 @@ template <int PREC> struct LdsQ {
   static constexpr int WCOLS = CAP + 2;           // + two "kill" columns of -1e30: where padded keys point their taps
   static constexpr int WIN = WCOLS * WIN_PITCH * ENT;
   static constexpr int CELLS = CAP * WIN_PITCH;   // accumulation window: one 64-bit cell per table entry (+ kill columns)
-  static constexpr int PCK = NWAVE * 32 * (PREC == BEVR_PREC_BF16 ? 16 : 32);
-  // bf16 mode: the tile's Q and dO fragments live in LDS (fragment order, re-read every step) instead of 16 registers
-  static constexpr int QDO = PREC == BEVR_PREC_BF16 ? NCOL * 4 * 64 * 16 : 16;     // per-wave (column, key) constants
+  static constexpr int PCK = NWAVE * 32 * (PREC == BEVR_PREC_BF16 ? 16 : 32);   // per wave: one 32-key half at a time
+  // bf16 mode: the tile's dO fragments live in LDS (fragment order, re-read every step) instead of 8 registers
+  static constexpr int QDO = PREC == BEVR_PREC_BF16 ? NCOL * 2 * 64 * 16 : 16;     // per-wave (column, key) constants
   static constexpr int ACCB = PREC == BEVR_PREC_BF16 ? 4 : 8;   // bytes per accumulation cell (see AccCell)
-  static constexpr int TOTAL = 2 * BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK + QDO;
+  static constexpr int TOTAL = BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK + QDO;
 };
 
 
@@ -102,7 +104,7 @@ template <> struct AccCell<BEVR_PREC_BF16> {
 };
 
 template <int PREC>
-__global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
+__global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Kt,
     const char* __restrict__ V, const char* __restrict__ key_ws,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const float* __restrict__ LSE,
@@ -112,9 +114,9 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   constexpr int EB = L::EB;
   constexpr int CAP = L::CAP;
   constexpr int ENT = L::ENT;
-  static_assert(L::TOTAL <= 160 * 1024, "LDS budget");
+  static_assert(L::TOTAL <= (PREC == BEVR_PREC_BF16 ? 80 : 160) * 1024, "LDS budget");
   // separate LDS objects: loads of the staged tiles / table window may be scheduled across the window atomics
-  __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
+  __shared__ __attribute__((aligned(16))) char smem[L::BUF];
   __shared__ __attribute__((aligned(16))) char win[L::WIN];
   typedef AccCell<PREC> Acc;
   typedef typename Acc::type acc_t;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   const int qb = prob / d.q_div;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
-  const int col = wave & (NCOL - 1), kh = wave / NCOL;
+  const int col = wave;
   CK* pck = pck_all + wave * 32;
   const int Mp = d.S * d.Sp;
   const int i0 = rb * 32;
@@ -182,14 +184,10 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     }
     dlt = 0.f;
   }
-  if constexpr (PREC == BEVR_PREC_BF16) {
-    if (kh == 0) {
-      u32x4* qd = reinterpret_cast<u32x4*>(qdo) + col * 4 * 64 + lane;
-      qd[0] = __builtin_bit_cast(u32x4, qf.v[0]);
-      qd[64] = __builtin_bit_cast(u32x4, qf.v[1]);
-      qd[128] = __builtin_bit_cast(u32x4, dof.v[0]);
-      qd[192] = __builtin_bit_cast(u32x4, dof.v[1]);
-    }
+  if constexpr (PREC == BEVR_PREC_BF16) {   // own lanes' data, written and read by this wave only
+    u32x4* qd = reinterpret_cast<u32x4*>(qdo) + col * 2 * 64 + lane;
+    qd[0] = __builtin_bit_cast(u32x4, dof.v[0]);
+    qd[64] = __builtin_bit_cast(u32x4, dof.v[1]);
   }
   const int ilane = i0 + lq;
   const int rowoff = ilane * 8;
@@ -209,23 +207,29 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   constexpr int NCHK = (NCHUNK + TQ - 1) / TQ;
   u32x4 st[NCHK];
   const int n_step = d.Np / KT;
-  const char* st_src[NCHK];
+  // a chunk slot's tile is uniform over its wave (CH and KT are multiples of 64): uniform base pointer and step
+  // stride, 32-bit per-thread byte offset
+  const char* st_base[NCHK];
+  unsigned st_off[NCHK];
   int st_inc[NCHK], st_dst[NCHK];
 #pragma unroll
   for (int k = 0; k < NCHK; ++k) {
     const int g = tid + k * TQ;
-    const int kind = g / CH, ci = g % CH;
+    const int kind = __builtin_amdgcn_readfirstlane(g / CH), ci = g % CH;
     if (kind < 2) {
-      st_src[k] = (kind ? Vh : Kh) + (size_t)ci * 16;
+      st_base[k] = kind ? Vh : Kh;
       st_inc[k] = CH * 16;
+      st_off[k] = (unsigned)ci * 16;
       st_dst[k] = kind * L::R_BYTES + (ci / RCH_ROW) * L::R_STRIDE + (ci % RCH_ROW) * 16;
     } else if (kind == 2) {
-      st_src[k] = Kth + ((size_t)(ci / TCH_ROW) * d.Np) * EB + (ci % TCH_ROW) * 16;
+      st_base[k] = Kth;
       st_inc[k] = KT * EB;
-      st_dst[k] = 2 * L::R_BYTES + (ci / TCH_ROW) * L::T_STRIDE + (ci % TCH_ROW) * 16;
+      st_off[k] = (unsigned)(((size_t)(ci / TCH_ROW) * d.Np) * EB + (ci % TCH_ROW) * 16);
+      st_dst[k] = 2 * L::R_BYTES + L::T_BYTES * 0 + (ci / TCH_ROW) * L::T_STRIDE + (ci % TCH_ROW) * 16;
     } else {
-      st_src[k] = reinterpret_cast<const char*>(kws + min(ci, KT - 1));
+      st_base[k] = reinterpret_cast<const char*>(kws);
       st_inc[k] = KT * 16;
+      st_off[k] = (unsigned)min(ci, KT - 1) * 16;
       st_dst[k] = g < NCHUNK ? 2 * L::R_BYTES + L::T_BYTES + ci * 16 : -1;   // past the last chunk: idle
     }
   }
@@ -233,19 +237,19 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   auto stage_load = [&](int step) {
 #pragma unroll
     for (int k = 0; k < NCHK; ++k) {
-      if (st_dst[k] >= 0) st[k] = *reinterpret_cast<const u32x4*>(st_src[k]);
-      st_src[k] += st_inc[k];
+      unsigned o = st_off[k];
+      asm volatile("" : "+v"(o));   // keep the per-thread part a 32-bit offset (no hoisted 64-bit pointer to spill)
+      if (st_dst[k] >= 0) st[k] = *reinterpret_cast<const u32x4*>(st_base[k] + (size_t)step * st_inc[k] + o);
     }
   };
-  auto stage_store = [&](int buf, int step) {
-    char* base = smem + buf * L::BUF;
+  auto stage_store = [&]() {
+    char* base = smem;
 #pragma unroll
     for (int k = 0; k < NCHK; ++k)
       if (st_dst[k] >= 0) *reinterpret_cast<u32x4*>(base + st_dst[k]) = st[k];
   };
 
   stage_load(0);
-  stage_store(0, 0);
   if (tid < 2 * WIN_PITCH) {   // the two kill columns of the table window; their accumulation cells only ever get +0
     if constexpr (PREC == BEVR_PREC_BF16)
       *reinterpret_cast<unsigned*>(win + (CAP * WIN_PITCH + tid) * ENT) = pack_bf16x2(BEVR_NEG_BIG, BEVR_NEG_BIG);
@@ -280,8 +284,11 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
   StepBox sb_cur = kbox[0], sb_nxt = kbox[min(1, n_step - 1)];
   for (int step = 0; step < n_step; ++step) {
     PROF_T(t0);
-    const int buf = step & 1;
-    const char* base = smem + buf * L::BUF;
+    // single staging buffer: the registers hold this step's tiles (loaded during the previous step); every wave
+    // finished reading the previous tiles at the barrier that ended the previous step
+    const char* base = smem;
+    stage_store();
+    __syncthreads();
     if (step + 1 < n_step) stage_load(step + 1);
     const WinInfo wi = make_wininfo(sb_cur, jrx_lo, jrx_hi, CAP);   // uniform: scalar loads, one step ahead
     sb_cur = sb_nxt;
@@ -307,23 +314,25 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
     }
     PROF_T(t1);
     PROF_ADD(0, t1 - t0);
-    const KeyW* kc = reinterpret_cast<const KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES) + kh * 32;
-    if (use_win) {
-      // this wave's (column, key) constants for its 32 keys of the step: lane & 31 = key (both halves write
-      // the same values); read back by this wave only -- a wave's LDS operations execute in order
-      const KeyW kw = kc[lq];
-      const float tx = jrx + (kw.b - (float)rg.ax0);
-      const float xf = floorf(tx);
-      CK e;
-      const bool dead = step * KT + kh * 32 + lq >= d.N;   // padded key: taps in the kill column => P = 0
-      const float fx = tx - xf, fy = kw.fy;
-      if (dead) e.set(1.f, 0.f, 0.f, 0.f);
-      else e.set((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy, fx * (1.0f - fy), fx * fy);
-      e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (wi.amin - rg.ay0);
-      pck[lq] = e;
-    }
+    const KeyW* kc0 = reinterpret_cast<const KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES);
 
-    {
+#pragma unroll 1
+    for (int kh = 0; kh < 2; ++kh) {   // the two 32-key halves of the step, one after the other
+      const KeyW* kc = kc0 + kh * 32;
+      if (use_win) {
+        // this wave's (column, key) constants for the 32 keys of this half: lane & 31 = key (both lane halves write
+        // the same values); read back by this wave only -- a wave's LDS operations execute in order
+        const KeyW kw = kc[lq];
+        const float tx = jrx + (kw.b - (float)rg.ax0);
+        const float xf = floorf(tx);
+        CK e;
+        const bool dead = step * KT + kh * 32 + lq >= d.N;   // padded key: taps in the kill column => P = 0
+        const float fx = tx - xf, fy = kw.fy;
+        if (dead) e.set(1.f, 0.f, 0.f, 0.f);
+        else e.set((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy, fx * (1.0f - fy), fx * fy);
+        e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (wi.amin - rg.ay0);
+        pck[lq] = e;
+      }
       Frag<PREC> kf, vkf, ktf;
       kf.load(base + (kh * 32 + lq) * L::R_STRIDE, hi);
       vkf.load(base + L::R_BYTES + (kh * 32 + lq) * L::R_STRIDE, hi);
@@ -340,13 +349,11 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
         for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
       }
       if constexpr (PREC == BEVR_PREC_BF16) {
-        const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 4 * 64 + lane;
-        Frag<PREC> qs, dos;
-        qs.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
-        qs.v[1] = __builtin_bit_cast(bf16x8, qd[64]);
-        dos.v[0] = __builtin_bit_cast(bf16x8, qd[128]);
-        dos.v[1] = __builtin_bit_cast(bf16x8, qd[192]);
-        s = mma_frag(kf, qs, s);        // S^T - LSE
+        const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 2 * 64 + lane;
+        Frag<PREC> dos;
+        dos.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
+        dos.v[1] = __builtin_bit_cast(bf16x8, qd[64]);
+        s = mma_frag(kf, qf, s);        // S^T - LSE
         dp = mma_frag(vkf, dos, dp);    // dP^T - delta
       } else {
         s = mma_frag(kf, qf, s);
@@ -365,7 +372,8 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
           a = *reinterpret_cast<const tap_t*>(p);
           b = *reinterpret_cast<const tap_t*>(p + WIN_PITCH * ENT);
         };
-        CK e0 = pck[crow(0, hi)], e1 = pck[crow(1, hi)];
+        const CK* pk = pck;
+        CK e0 = pk[crow(0, hi)], e1 = pk[crow(1, hi)];
         tap_t ta, tb;
         read_tap(e0.cell, ta, tb);
 #pragma unroll
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
           tap_t na = ta, nb = tb;
           CK e2 = e1;
           if (r + 1 < 16) read_tap(e1.cell, na, nb);
-          if (r + 2 < 16) e2 = pck[crow(r + 2, hi)];
+          if (r + 2 < 16) e2 = pk[crow(r + 2, hi)];
           float sv;
           if constexpr (PREC == BEVR_PREC_BF16) {
             sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ta), __builtin_bit_cast(bf16x2, e0.wA), s[r],
@@ -431,41 +439,28 @@ __global__ __launch_bounds__(TQ) void attn_bwd_q_kernel(
       PROF_ADD(6, t3b - t3);
     }
 
-    if (step + 1 < n_step) stage_store(buf ^ 1, step + 1);
     PROF_T(t4);
-    __syncthreads();
+    __syncthreads();   // every wave is done with the staged tiles (and with the region, should the next step move it)
     PROF_T(t5);
     PROF_ADD(3, t4 - t1);
     PROF_ADD(4, t5 - t4);
     PROF_ADD(7, 1);
   }
 #ifdef BEVR_PROF
-  if (lane == 0 && (wave == 0 || wave == 15)) {
+  if (lane == 0 && (wave == 0 || wave == NWAVE - 1)) {
     for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof[(wave ? 8 : 0) + i], pacc[i]);
   }
 #endif
   flush_and_clear(rg, acc_live);
 
-  // ---- merge the two key halves' dQ partial sums (waves w and w + 8) through LDS, then store ------------
-  // the exchange needs 8 waves x 16 x 64 floats = 32 KiB: split over the (dead) staging area and table window
-  __syncthreads();
-  auto xptr = [&](int c, int r) -> float* {
-    float* basep = c < 4 ? reinterpret_cast<float*>(smem) : reinterpret_cast<float*>(win);
-    return basep + (((c & 3) * 16 + r) * 64 + lane);
-  };
-  static_assert(2 * L::BUF >= 4 * 16 * 64 * 4 && L::WIN >= 4 * 16 * 64 * 4, "exchange halves");
-  if (kh == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) *xptr(col, r) = dq[r];
-  }
-  __syncthreads();
-  if (kh == 0 && live) {
+  // ---- store dQ (ln2 of dS = ln2 P (dP - delta) applied here) -----------------------------------------------
+  if (live) {
     float* row = dQ + ((size_t)ph * Mp + (size_t)jcol * d.Sp + i0 + lq) * 32;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = BEVR_LN2 * (dq[4 * g4 + k] + *xptr(col, 4 * g4 + k));
+      for (int k = 0; k < 4; ++k) v[k] = BEVR_LN2 * dq[4 * g4 + k];
       *reinterpret_cast<f32x4*>(row + 8 * g4 + 4 * hi) = v;
     }
   }

@@ -265,9 +265,10 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       float tm = s[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
-      tm = fmaxf(tm, __shfl_xor(tm, 32));
       const bool first = (step == 0 && ks == 0);
       if (first || __any(tm > RESCALE_THR)) {   // wave-uniform: rare after the first tiles
+        // the two lane halves hold the same queries (different keys): agree on the maximum only when it is needed
+        tm = fmaxf(tm, __shfl_xor(tm, 32));
         const float up = first ? tm : fmaxf(tm, 0.f);   // the max only moves up, except when it is first set
         const float al = fast_exp2(-up);
 #pragma unroll
@@ -275,14 +276,15 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
         l *= al;
         m += up;
       }
-      float ls = 0.f;
+      f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = fast_exp2(s[r]);
-        s[r] = p;
-        ls += p;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 pp = {fast_exp2(s[r]), fast_exp2(s[r + 1])};
+        s[r] = pp[0];
+        s[r + 1] = pp[1];
+        ls2 += pp;
       }
-      l += ls;
+      l += ls2[0] + ls2[1];
       o = mma_acc_b(vf, s, o);
     }
 

@@ -14,7 +14,8 @@ proj = BEV2CameraProjector(imu_to_rgb={0: T}, K={0: K}, vehicle_type_code=0, img
                            ori_img_width=704, ori_img_height=256, device=dev)
 sca = SpatialCrossAttn({"X": 50, "Y": 50, "Z": 2}, proj, S, D, -1.0, C, h, 1, 1, 3, B, True, n_views=V, precision="bf16").to(dev)
 for m in sca.modules():
-    if isinstance(m, torch.nn.Conv2d):
+    # WIDE=1: large learned offsets (keys scattered over the table: the fallback paths); default: module init
+    if os.environ.get("WIDE") and isinstance(m, torch.nn.Conv2d):
         torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 q = torch.randn(B, C, S, S, device=dev, requires_grad=True)
 feat = torch.randn(B * V, C, 64, 176, device=dev, requires_grad=True)

@@ -55,6 +55,9 @@ CORE_CFGS = [
     (1, 2, 16, 4, 2, 6, 2, 50),
     (1, 1, 64, 2, 1, 10, 5, 70),
     (1, 3, 64, 2, 1, 34, 2, 300),     # two row blocks, ragged columns, several views
+    # table 1599 columns wide, keys all over it: no step fits the LDS table windows (forward / query-side backward
+    # fall back to global gathers and atomics) and no key block fits the key-side ring (gather kernel)
+    (1, 1, 32, 1, 1, 8, 100, 128),
 ]
 
 

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   const char* Kth = Kt + ((size_t)ph * 32) * d.Np * EB;
   const int pg = prob * d.groups + grp;
   const KeyW* kws = reinterpret_cast<const KeyW*>(key_ws) + (size_t)pg * d.Np;
-  const StepBox* kbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / KT);
+  const StepBox* kbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / 32);
   const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
   float* dtb = dtable + (size_t)hd * d.Wp * (d.Hp + 1);
   const int Hp8 = d.Hp * 8;
@@ -281,7 +281,9 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
 #ifdef BEVR_PROF
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  StepBox sb_cur = kbox[0], sb_nxt = kbox[min(1, n_step - 1)];
+  // boxes of the two 32-key halves of a step: uniform (scalar loads), fetched one step ahead
+  StepBox sb_cur[2] = {kbox[0], kbox[1]};
+  StepBox sb_nxt[2] = {kbox[2 * min(1, n_step - 1)], kbox[2 * min(1, n_step - 1) + 1]};
   for (int step = 0; step < n_step; ++step) {
     PROF_T(t0);
     // single staging buffer: the registers hold this step's tiles (loaded during the previous step); every wave
@@ -290,28 +292,13 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
     stage_store();
     __syncthreads();
     if (step + 1 < n_step) stage_load(step + 1);
-    const WinInfo wi = make_wininfo(sb_cur, jrx_lo, jrx_hi, CAP);   // uniform: scalar loads, one step ahead
-    sb_cur = sb_nxt;
-    sb_nxt = kbox[min(step + 2, n_step - 1)];
-    const bool use_win = wi.ok != 0;   // workgroup-uniform
-    if (use_win && !region_contains(rg, wi, CAP)) {
-      // every wave finished the previous step (barrier at the end of the loop body): safe to drain and move
-      flush_and_clear(rg, acc_live);
-      rg = region_anchor(wi, d, i0, CAP);
-      {   // fill the region: one wave-wide load per table column (lane = row)
-        const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
-        for (int c = wave; c < CAP; c += NWAVE) {
-          f32x2 v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)(rg.ax0 + c + d.x_off) * d.Hp + y0) * 8);
-          if constexpr (PREC == BEVR_PREC_BF16)
-            *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
-          else
-            *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = v;
-        }
-      }
-      acc_live = true;
-      __syncthreads();
-      PROF_ADD(5, 1);
-    }
+    const StepBox sb0 = sb_cur[0], sb1 = sb_cur[1];
+    sb_cur[0] = sb_nxt[0];
+    sb_cur[1] = sb_nxt[1];
+    sb_nxt[0] = kbox[2 * min(step + 2, n_step - 1)];
+    sb_nxt[1] = kbox[2 * min(step + 2, n_step - 1) + 1];
+    // if the whole step's box fits, both halves share one region test (fewer moves); else the halves go separately
+    const WinInfo wi_step = make_wininfo(box_union(sb0, sb1), jrx_lo, jrx_hi, CAP);
     PROF_T(t1);
     PROF_ADD(0, t1 - t0);
     const KeyW* kc0 = reinterpret_cast<const KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES);
@@ -319,6 +306,28 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
 #pragma unroll 1
     for (int kh = 0; kh < 2; ++kh) {   // the two 32-key halves of the step, one after the other
       const KeyW* kc = kc0 + kh * 32;
+      // ---- this half's table window ------------------------------------------------------------------
+      const StepBox sbh = kh ? sb1 : sb0;
+      const WinInfo wi = wi_step.ok ? wi_step : make_wininfo(sbh, jrx_lo, jrx_hi, CAP);
+      const bool use_win = wi.ok != 0;   // workgroup-uniform
+      if (use_win && !region_contains(rg, wi, CAP)) {
+        if (kh) __syncthreads();   // mid-step move: every wave must be done with the first half's taps and adds
+        flush_and_clear(rg, acc_live);
+        rg = region_anchor(wi, d, i0, CAP);
+        {   // fill the region: one wave-wide load per table column (lane = row)
+          const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
+          for (int c = wave; c < CAP; c += NWAVE) {
+            f32x2 v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)(rg.ax0 + c + d.x_off) * d.Hp + y0) * 8);
+            if constexpr (PREC == BEVR_PREC_BF16)
+              *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
+            else
+              *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = v;
+          }
+        }
+        acc_live = true;
+        __syncthreads();
+        PROF_ADD(5, 1);
+      }
       if (use_win) {
         // this wave's (column, key) constants for the 32 keys of this half: lane & 31 = key (both lane halves write
         // the same values); read back by this wave only -- a wave's LDS operations execute in order
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
         const float fx = tx - xf, fy = kw.fy;
         if (dead) e.set(1.f, 0.f, 0.f, 0.f);
         else e.set((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy, fx * (1.0f - fy), fx * fy);
-        e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (wi.amin - rg.ay0);
+        e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (sbh.amin - rg.ay0);   // arow8 is relative to the half's first row
         pck[lq] = e;
       }
       Frag<PREC> kf, vkf, ktf;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   const char* Vh = Vt + ((size_t)ph * 32) * d.Np * EB;
   const int pg = prob * d.groups + grp;
   const KeyW* kws = reinterpret_cast<const KeyW*>(key_ws) + (size_t)pg * d.Np;
-  const StepBox* kbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / KT);
+  const StepBox* kbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / 32);
   const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
   const int Hp8 = d.Hp * 8;
   const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
@@ -167,17 +167,24 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   rg.ax0 = -(1 << 28);   // nothing contained: the first windowed step anchors
   rg.ay0 = 0;
 
-  StepBox sb_cur = kbox[0], sb_nxt = kbox[min(1, n_step - 1)];
+  // boxes of the two 32-key halves of a step: uniform (scalar loads), fetched one step ahead
+  StepBox sb_cur[2] = {kbox[0], kbox[1]};
+  StepBox sb_nxt[2] = {kbox[2 * min(1, n_step - 1)], kbox[2 * min(1, n_step - 1) + 1]};
   for (int step = 0; step < n_step; ++step) {
     const int buf = step & 1;
     const char* base = smem + buf * L::BUF;
     if (step + 1 < n_step) stage_load(step + 1);
     const KeyW* kws = reinterpret_cast<const KeyW*>(base + L::K_BYTES + L::V_BYTES);
-    const WinInfo wi = make_wininfo(sb_cur, jrx_lo, jrx_hi, WIN_COLS);   // uniform: scalar loads, one step ahead
-    sb_cur = sb_nxt;
-    sb_nxt = kbox[min(step + 2, n_step - 1)];
-    const bool use_win = wi.ok != 0;   // workgroup-uniform
-    if (use_win && !region_contains(rg, wi, WIN_COLS)) {
+    const StepBox sb0 = sb_cur[0], sb1 = sb_cur[1];
+    sb_cur[0] = sb_nxt[0];
+    sb_cur[1] = sb_nxt[1];
+    sb_nxt[0] = kbox[2 * min(step + 2, n_step - 1)];
+    sb_nxt[1] = kbox[2 * min(step + 2, n_step - 1) + 1];
+    // if the whole step's box fits (the common case) both halves share one region test and one pass of per-key
+    // constants; otherwise the halves are windowed separately
+    const WinInfo wi_step = make_wininfo(box_union(sb0, sb1), jrx_lo, jrx_hi, WIN_COLS);
+    auto move_region = [&](const WinInfo& wi, bool mid_step) {
+      if (mid_step) __syncthreads();   // every wave must be done with the first half's taps
       rg = region_anchor(wi, d, i0, WIN_COLS);
       // fill the region: one wave-wide load per table column (lane = row)
       const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
@@ -189,21 +196,35 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
           *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = v;
       }
       __syncthreads();
-    }
-    if (use_win) {
-      // this wave's (column, key) constants for the step: lane = key
-      const KeyW kw = kws[lane];
+    };
+    // this wave's (column, key) constants: key slot `ki` of the step, whose half starts at table row `amin_h`
+    auto key_consts = [&](int ki, int amin_h) {
+      const KeyW kw = kws[ki];
       const float tx = jrx + (kw.b - (float)rg.ax0);
       const float xf = floorf(tx);
       CK e;
       const float fx = tx - xf, fy = kw.fy;
       e.set((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy, fx * (1.0f - fy), fx * fy);
-      e.cell = (int)xf * (WIN_PITCH * ENT) + ((kw.arow8 >> 3) + (wi.amin - rg.ay0)) * ENT;
-      pck[lane] = e;   // read back by this wave only: LDS operations of a wave execute in order
+      e.cell = (int)xf * (WIN_PITCH * ENT) + ((kw.arow8 >> 3) + (amin_h - rg.ay0)) * ENT;   // arow8: relative to the half
+      pck[ki] = e;   // read back by this wave only: LDS operations of a wave execute in order
+    };
+    if (wi_step.ok) {
+      if (!region_contains(rg, wi_step, WIN_COLS)) move_region(wi_step, false);
+      key_consts(lane, hi ? sb1.amin : sb0.amin);   // lane = key
     }
 
 #pragma unroll
     for (int ks = 0; ks < KT / 32; ++ks) {
+      bool use_win = wi_step.ok != 0;   // workgroup-uniform
+      if (!wi_step.ok) {
+        const StepBox sbh = ks ? sb1 : sb0;
+        const WinInfo wi = make_wininfo(sbh, jrx_lo, jrx_hi, WIN_COLS);
+        use_win = wi.ok != 0;
+        if (use_win) {
+          if (!region_contains(rg, wi, WIN_COLS)) move_region(wi, ks != 0);
+          key_consts(ks * 32 + lq, sbh.amin);   // lane & 31 = key (both lane halves write the same value)
+        }
+      }
       Frag<PREC> kf, vf;
       kf.load(base + (ks * 32 + lq) * L::K_STRIDE, hi);
       load_perm(vf, base + L::K_BYTES + lq * L::V_STRIDE + ks * 32 * EB, hi);

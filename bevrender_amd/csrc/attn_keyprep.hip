@@ -1,6 +1,7 @@
 // Key preparation for the query-stationary attention kernels (forward, query-side backward).
 // One wave per 64-key step: clamps the keys' table coordinates, splits them into the integer row / fractional
-// parts the kernels consume (KeyW) and reduces the step's bounding box (StepBox).  Done once per attention call
+// parts the kernels consume (KeyW) and reduces the bounding box of each 32-key half of the step (StepBox; the
+// reductions run inside a 32-lane half).  Done once per attention call
 // instead of once per (query tile, step) inside the kernels, where the reductions sat on every workgroup's
 // per-step critical path.
 #include "attn_tile.h"
@@ -9,22 +10,22 @@ namespace {
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = min(v, __shfl_xor(v, s));
+  for (int s = 16; s > 0; s >>= 1) v = min(v, __shfl_xor(v, s));
   return v;
 }
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = max(v, __shfl_xor(v, s));
+  for (int s = 16; s > 0; s >>= 1) v = max(v, __shfl_xor(v, s));
   return v;
 }
 __device__ __forceinline__ float wave_min_f(float v) {
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = fminf(v, __shfl_xor(v, s));
+  for (int s = 16; s > 0; s >>= 1) v = fminf(v, __shfl_xor(v, s));
   return v;
 }
 __device__ __forceinline__ float wave_max_f(float v) {
 #pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+  for (int s = 16; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
   return v;
 }
 
@@ -54,10 +55,10 @@ __global__ __launch_bounds__(256) void attn_keyprep_kernel(bevr_attn_desc d, con
   k.b = live ? b : bmin;   // dead (padded) keys: any in-window column; their logits are masked anyway
   k.arow8 = live ? (A - amin) * 8 : 0;
   kw_out[idx] = k;
-  if (lane == 0) {
+  if ((lane & 31) == 0) {
     StepBox sb;
     sb.amin = amin; sb.amax = amax; sb.bmin = bmin; sb.bmax = bmax;
-    box_out[gw] = sb;
+    box_out[2 * gw + (lane >> 5)] = sb;
   }
 }
 
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_keyprep_kernel(bevr_attn_desc d, con
 
 extern "C" size_t bevr_attn_key_ws_bytes(const bevr_attn_desc* d) {
   if (bevr_check_desc(d)) return 0;
-  return key_ws_box_offset(*d) + (size_t)d->n_prob * d->groups * (d->Np / KT) * sizeof(StepBox);
+  return key_ws_box_offset(*d) + (size_t)d->n_prob * d->groups * (d->Np / 32) * sizeof(StepBox);
 }
 
 extern "C" int bevr_attn_key_prep(const bevr_attn_desc* d, const float* key_a, const float* key_b, void* key_ws,

@@ -36,7 +36,7 @@ struct WinInfo {
   int pad0, pad1;
 };
 
-// bounding box of a step's live keys, written by the key-preparation kernel (attn_keyprep.hip)
+// bounding box of the live keys of one 32-key half of a step, written by the key-preparation kernel (attn_keyprep.hip)
 struct StepBox {
   int amin, amax;      // min / max floor(a); amax < amin: the step has no live key
   float bmin, bmax;
@@ -44,9 +44,19 @@ struct StepBox {
 
 // Byte layout of the key workspace handed between bevr_attn_key_prep and the query-stationary kernels:
 //   KeyW   [n_prob * groups][Np]        then
-//   StepBox[n_prob * groups][Np / KT]
+//   StepBox[n_prob * groups][Np / 32]   one box per 32-key half of a step: the halves are windowed separately
 __host__ __device__ __forceinline__ size_t key_ws_box_offset(const bevr_attn_desc& d) {
   return (size_t)d.n_prob * d.groups * d.Np * sizeof(KeyW);
+}
+
+// Union of the two halves' boxes of a step (an empty half has amax < amin and huge bmin / -huge bmax: neutral).
+__device__ __forceinline__ StepBox box_union(const StepBox& a, const StepBox& b) {
+  StepBox u;
+  u.amin = min(a.amin, b.amin);
+  u.amax = max(a.amax, b.amax);
+  u.bmin = fminf(a.bmin, b.bmin);
+  u.bmax = fmaxf(a.bmax, b.bmax);
+  return u;
 }
 
 // The table box a (query tile) x (key step) block needs, from the step's key box and the tile's column range.

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -131,16 +132,18 @@ def pack_table(rpe_table: torch.Tensor, g: AttnGeom) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------
 # key ordering (host, init time)
 # --------------------------------------------------------------------------------------------------
-def kd_key_order(pos_ref, S: int, Wt: int, leaf: int = 64):
+def kd_key_order(pos_ref, S: int, Wt: int, leaf: int = 32):
     """Order keys so that every run of `leaf` consecutive keys is spatially compact in rpe-table space.
 
     pos_ref (N, 2) STATIC key positions (y, x) in [-1, 1] units (camera projections of the pillar grid for
     SCA, the regular grid for TSA; learned offsets move a key by a few table cells only).  Returns a
     permutation (numpy int64, length N) from a k-d tree: split the longer table-space extent at a multiple
     of `leaf` until a node holds <= leaf keys.  Softmax attention is invariant to the order of its keys,
-    so this changes no result; it bounds the table window a 64-key step needs (csrc/attn_tile.h).
+    so this changes no result; it bounds the table window a 32-key half of a step needs (csrc/attn_tile.h: the
+    kernels window the two halves of a 64-key step separately).
     """
     import numpy as np
+    leaf = int(os.environ.get("BEVR_KD_LEAF", leaf))
     pr = np.asarray(pos_ref, dtype=np.float64)
     a = (1.0 - pr[:, 0]) * ((S - 1) / 2.0)
     b = (1.0 - pr[:, 1]) * ((Wt - 1) / 4.0)

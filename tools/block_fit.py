@@ -12,7 +12,7 @@ p2d = orc.bev_grid_to_camera(pts, T, K, 704, 256, 704, 256)
 ref = orc.sca_reference_points(p2d, 1)[0]          # (V, h, w*d, 2) (x, y)
 Wt = 2 * S * D - 1
 Sp = 32 * ((S + 31) // 32)
-for blk, wcap in ((256, 14336), (256, 10240), (128, 14336), (512, 30000)):
+for blk, wcap in ((384, 30720), (192, 14336), (192, 20480)):
     fit = tot = 0
     needs, rows = [], []
     for v in range(V):
@@ -27,8 +27,8 @@ for blk, wcap in ((256, 14336), (256, 10240), (128, 14336), (512, 30000)):
             A = np.floor(a[k0:k0 + blk]); bb = b[k0:k0 + blk]
             r = int(A.max() - A.min()) + Sp + 1
             pitch = r | 1
-            ncw = wcap // pitch
-            need = int(math.floor(bb.max() - bb.min())) + 4
+            ncw = wcap // pitch - 1
+            need = int(math.floor(bb.max() - bb.min())) + 4 + 6 + 1
             tot += 1; fit += ncw >= need
             needs.append(need); rows.append(r)
     print(f"blk {blk} wcap {wcap}: fit {fit}/{tot} = {fit/tot:.3f}; need cols p50 {np.percentile(needs,50)} p90 {np.percentile(needs,90)} max {max(needs)}; rows p50 {np.percentile(rows,50)} p90 {np.percentile(rows,90)}")

@@ -254,9 +254,17 @@ def main():
             flops = rec["flops"] / rec["n"]
             ach = flops / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
+            # HBM bytes per launch of that kernel: measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
+            # very command (separate passes, gfx950 correction applied; see profiles/r01_traffic.json), not live
+            traffic = None
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+            if S == 200 and B == 4 and args.precision == "bf16" and os.path.exists(tpath):
+                with open(tpath) as fh:
+                    traffic = json.load(fh)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+            pairs = rec["flops"] / rec["n"] / (2.0 * 32 * {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4}[dom])
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 5), "traffic": None, "avg_ms": round(avg_ms, 3),
-                    "launches": rec["n"],
+                    "frac": round(ach / peak, 5), "traffic": traffic, "avg_ms": round(avg_ms, 3),
+                    "launches": rec["n"], "pair_ops_per_s": round(pairs / (avg_ms * 1e-3), 0),
                     "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 2) for k, v in sorted(ktimes.items())}}
         out = {
             "metric": "samples/sec fwd+bwd, 6-cam 256x704 BEV-lift+corr",

@@ -403,8 +403,14 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
       // the taps are read as aligned register pairs (rows k, k+1) and (rows k+1, k+2)
       const f32x2 wy2 = {wy0[w], wy0[w]}, fy2 = {fy[w], fy[w]}, fx2 = {fx[w], fx[w]};
       f32x2 sa2 = {0.f, 0.f}, sb2 = {0.f, 0.f};
+      const int n_live = d.S - rb * 32;   // query rows of this tile inside the grid (the last tile of a column is partial)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
+        if (8 * g4 >= n_live) {   // rows 8 g4 .. 8 g4 + 7 are all padding: no bias, no exp; they contribute nothing
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { s[4 * g4 + k] = 0.f; dp[4 * g4 + k] = 0.f; }
+          continue;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int r = 4 * g4 + 2 * h, o = (8 * g4 + 2 * h) * 4;

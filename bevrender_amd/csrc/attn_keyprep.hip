@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void attn_keyprep_kernel(bevr_attn_desc d, con
   KeyW k;
   k.aoff = ((A + d.y_off) + d.x_off * d.Hp) * 8;
   k.fy = a - af;
-  k.b = live ? b : bmin;   // dead (padded) keys: any in-window column; their logits are masked anyway
+  // dead (padded) keys: any in-window column (their logits are masked anyway); a half without any live key has no
+  // box, so pin them to column 0 rather than to the reduction's identity
+  k.b = live ? b : (amax >= amin ? bmin : 0.f);
   k.arow8 = live ? (A - amin) * 8 : 0;
   kw_out[idx] = k;
   if ((lane & 31) == 0) {

@@ -92,7 +92,7 @@ __device__ __forceinline__ KBox wg_key_box(int a_lo, int a_hi, float b_lo, float
 // Ring geometry of a block's table slab; `fits` decides which kernel owns the block.
 struct Slab {
   int rows;     // Amax - Amin + Sp + 1: window row w is padded table row Amin + y_off + w
-  int pitch;    // rows | 1 (odd: spreads the lanes' columns over the banks)
+  int pitch;    // rows rounded up to 7 (mod 32): spreads the lanes' columns over the banks
   int ncw;      // ring capacity in table columns
   bool fits;
 };
@@ -103,7 +103,9 @@ __device__ __forceinline__ Slab make_slab(const KBox& kb, const bevr_attn_desc& 
     return sl;
   }
   sl.rows = kb.amax - kb.amin + d.Sp + 1;
-  sl.pitch = sl.rows | 1;
+  // pitch = 7 (mod 32): a compact cluster of keys (column slot s, row a) then lands on banks 7 s + a, nearly all
+  // distinct -- measured 4 % faster than an arbitrary odd pitch (bank conflicts were 36 % of the LDS-active cycles)
+  sl.pitch = sl.rows + ((7 - sl.rows) & 31);
   sl.ncw = wcap / sl.pitch - 1;   // the last column of the LDS array is the "kill" column of padded keys
   // columns of one BEV column's range plus those of the next (prefetched while this one is in use), plus slack
   const int need = (int)floorf(kb.bmax - kb.bmin) + 4 + (int)rx_ceil + 1;

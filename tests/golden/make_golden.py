@@ -19,7 +19,8 @@ Fixtures (fp32, seeded):
   G2 sca_*.npz      SCADeformableAttention   model/SCA_deform_attn.py:180-421 (n_views=1)
   G3 proj_*.npz     sample_3d_points + bev_grid_to_camera  model/SCA.py:112-162, model/bev_cmr_proj.py:61-124
   G4 enclayer.npz   EncoderLayer fwd+bwd (train mode, drop 0)  model/encoder.py:339-411
-  G5 recall.npz     Trainer.get_recall        train.py:551-572
+  G5 full_bevrender.npz  full BEVRender fwd+bwd, T=2, S=28 (separate script: make_golden_full.py)  model/bevrender.py:14-221
+  G7 recall.npz     Trainer.get_recall        train.py:551-572
 """
 import argparse
 import os

@@ -110,3 +110,21 @@ def test_kd_key_order_is_a_permutation_with_compact_leaves():
         area_sorted.append((np.ptp(a[k:k + 64]) + 1) * (np.ptp(b[k:k + 64]) + 1))
         area_nat.append((np.ptp(a0[k:k + 64]) + 1) * (np.ptp(b0[k:k + 64]) + 1))
     assert np.median(area_sorted) * 20 < np.median(area_nat)
+
+
+def test_full_model_constructs_on_cpu_with_the_reference_state_dict_layout():
+    """The G5 fixture was made by loading this model's state dict into the reference model with strict=True:
+    452 entries, 1 990 436 parameters (tests/golden/make_golden_full.py).  Construction needs no GPU."""
+    import importlib.util
+    import logging
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mgf", os.path.join(here, "golden", "make_golden_full.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    z = np.load(os.path.join(here, "golden", "full_bevrender.npz"))
+    from bevrender_amd.model.bevrender import BEVRender
+    torch.manual_seed(int(z["seed"]))
+    model = BEVRender(g.full_config(), logging.getLogger("t"), "train")
+    assert len(model.state_dict()) == int(z["n_state"]) == 452
+    assert sum(p.numel() for p in model.parameters()) == 1990436

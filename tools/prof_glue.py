@@ -1,0 +1,16 @@
+"""torch.profiler view of one benchmark step: device time by operator, attention kernels excluded (the PyTorch glue)."""
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+import bench
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    bench.main()
+ka = prof.key_averages()
+rows = sorted(ka, key=lambda e: -e.self_device_time_total)
+tot = 0.0
+for e in rows[:45]:
+    if "attn" in e.key or "Memcpy" in e.key:
+        continue
+    print(f"{e.self_device_time_total/2e3:9.2f} ms/step {e.count//2:6d} calls/step  {e.key[:100]}")

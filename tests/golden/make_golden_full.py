@@ -84,5 +84,40 @@ def main():
     print("wrote full_bevrender.npz: out", tuple(out.shape), "sum", float(out.sum()), "n_state", len(sd))
 
 
+def decoder_input(S):
+    return torch.randn(2, 64, S, S, generator=torch.Generator().manual_seed(300 + S))
+
+
+def gen_decoder():
+    """G6: BEVImageRenderDecoder (model/decoder_img_render.py:4-93) at the three BEV sides it is defined for, train
+    mode (batch statistics).  Same seeded-weights scheme as G5; plain PyTorch on both sides, so this one runs on CPU."""
+    log = logging.getLogger("golden")
+    rec = {}
+    for S in (14, 28, 56):
+        for m in [k for k in sys.modules if k == "model" or k.startswith("model.")]:
+            del sys.modules[m]
+        sys.path.insert(0, ROOT)
+        from bevrender_amd.model.decoder_img_render import BEVImageRenderDecoder as Mine
+        torch.manual_seed(SEED + S)
+        sd = {k: v.clone() for k, v in Mine(bev_spatial_dim=S, model_dim=64, hid_dim=64).state_dict().items()}
+        sys.path.remove(ROOT)
+        sys.path.insert(0, "/root/reference")
+        from model.decoder_img_render import BEVImageRenderDecoder as Ref
+        ref = Ref(bev_spatial_dim=S, model_dim=64, hid_dim=64, logger=log)
+        ref.load_state_dict(sd, strict=True)
+        sys.path.remove("/root/reference")
+        ref.train()
+        out = ref(decoder_input(S)).detach()
+        oi = sample_index(out.numel(), 128, S)
+        rec[f"s{S}.shape"] = np.array(out.shape)
+        rec[f"s{S}.idx"] = oi.numpy()
+        rec[f"s{S}.val"] = out.flatten()[oi].numpy()
+        rec[f"s{S}.sum"] = out.double().sum().numpy()
+        rec[f"s{S}.n_state"] = len(sd)
+    np.savez_compressed(os.path.join(HERE, "decoder.npz"), seed=SEED, **rec)
+    print("wrote decoder.npz")
+
+
 if __name__ == "__main__":
     main()
+    gen_decoder()

@@ -128,3 +128,25 @@ def test_full_model_constructs_on_cpu_with_the_reference_state_dict_layout():
     model = BEVRender(g.full_config(), logging.getLogger("t"), "train")
     assert len(model.state_dict()) == int(z["n_state"]) == 452
     assert sum(p.numel() for p in model.parameters()) == 1990436
+
+
+def test_render_decoder_matches_reference_golden():
+    """G6: the render decoder (plain PyTorch / MIOpen module with the reference's parameter names) against the
+    reference's decoder at BEV side 14 / 28 / 56 (tests/golden/decoder.npz), seeded weights as in G5."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("mgf", os.path.join(here, "golden", "make_golden_full.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    z = np.load(os.path.join(here, "golden", "decoder.npz"))
+    from bevrender_amd.model.decoder_img_render import BEVImageRenderDecoder
+    for S in (14, 28, 56):
+        torch.manual_seed(int(z["seed"]) + S)
+        dec = BEVImageRenderDecoder(bev_spatial_dim=S, model_dim=64, hid_dim=64)
+        assert len(dec.state_dict()) == int(z[f"s{S}.n_state"])
+        dec.train()
+        out = dec(g.decoder_input(S)).detach()
+        assert tuple(out.shape) == tuple(z[f"s{S}.shape"]) == (2, 3, 224, 224)
+        np.testing.assert_allclose(out.flatten()[torch.tensor(z[f"s{S}.idx"])].numpy(), z[f"s{S}.val"], rtol=1e-4, atol=1e-5)
+        assert abs(out.double().sum().item() - float(z[f"s{S}.sum"])) < 1e-3 * out.numel() * 1e-2

@@ -237,7 +237,23 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
   }
   const KBox box = wg_key_box(a_lo, a_hi, b_lo, b_hi, red, TW / 64, wave, lane);
   const Slab sl = make_slab(box, d, L::WCAP, ceilf(rx));
-  if (!sl.fits) return;                  // the gather kernel owns this block (uniform exit)
+  if (!sl.fits) {
+    // the gather kernel owns this block; its workgroups split the query sweep and ADD their partial dK / dV, so
+    // the rows are cleared here (this kernel runs first on the stream)
+#pragma unroll
+    for (int w = 0; w < KWW; ++w) {
+      if (!wave_live[w]) continue;
+      float* kr = dK + ((size_t)ph * d.Np + key[w]) * 32;
+      float* vr = dV + ((size_t)ph * d.Np + key[w]) * 32;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        *reinterpret_cast<f32x4*>(kr + 8 * g4 + 4 * hi) = z;
+        *reinterpret_cast<f32x4*>(vr + 8 * g4 + 4 * hi) = z;
+      }
+    }
+    return;
+  }
   if (box.amax < box.amin) {             // only padded keys: their gradients are zero
 #pragma unroll
     for (int w = 0; w < KWW; ++w) {
@@ -506,6 +522,7 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
 // =========================================================================================================
 constexpr int TG = 256;   // 4 waves x 3 x 32 keys
 constexpr int KW = 3;
+constexpr int GSPLIT = 4;  // workgroups per key block: the few blocks on this path would otherwise run ~6 ms each, alone
 
 template <int PREC>
 __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
@@ -522,9 +539,10 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
   const int n_kb = (d.Np + KEYS_WG - 1) / KEYS_WG;
   const int n_ph = d.n_prob * d.heads;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int ph = (slot / n_kb) * 8 + xcd;
+  const int ph = (slot / (n_kb * GSPLIT)) * 8 + xcd;
   if (ph >= n_ph) return;
-  const int kblk = slot % n_kb;
+  const int kblk = (slot % (n_kb * GSPLIT)) / GSPLIT;
+  const int split = slot % GSPLIT;   // this workgroup's share of the query sweep
   const int prob = ph / d.heads, hd = ph % d.heads;
   const int grp = hd / (d.heads / d.groups);
   const int qb = prob / d.q_div;
@@ -592,13 +610,16 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
   qs.init(tid, Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB, dO + ((size_t)ph * Mp) * 32 * EB,
           Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB, dOt + ((size_t)ph * 32) * Mp * EB,
           LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp);
-  const int n_it = d.S * n_rb;
-  qs.load(tid, 0);
+  const int n_all = d.S * n_rb;
+  const int chunk = (n_all + GSPLIT - 1) / GSPLIT;
+  const int it_first = split * chunk, n_it = min(n_all, it_first + chunk);
+  if (it_first >= n_it) return;   // uniform
+  qs.load(tid, (size_t)(it_first / n_rb) * d.Sp + (it_first % n_rb) * 32);
   qs.store(tid, smem);
   __syncthreads();
 
-  for (int it = 0; it < n_it; ++it) {
-    const int buf = it & 1;
+  for (int it = it_first; it < n_it; ++it) {
+    const int buf = (it - it_first) & 1;
     const char* base = smem + buf * L::BUF;
     const int j = it / n_rb, i0 = (it % n_rb) * 32;
     if (it + 1 < n_it) {
@@ -668,11 +689,11 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
     float* vr = dV + ((size_t)ph * d.Np + key) * 32;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
-      f32x4 a, b;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { a[k] = dk[w][4 * g4 + k]; b[k] = dv[w][4 * g4 + k]; }
-      *reinterpret_cast<f32x4*>(kr + 8 * g4 + 4 * hi) = a;
-      *reinterpret_cast<f32x4*>(vr + 8 * g4 + 4 * hi) = b;
+      for (int k = 0; k < 4; ++k) {   // partial sums of this workgroup's share of the sweep (rows cleared by the window kernel)
+        atomicAdd(kr + 8 * g4 + 4 * hi + k, dk[w][4 * g4 + k]);
+        atomicAdd(vr + 8 * g4 + 4 * hi + k, dv[w][4 * g4 + k]);
+      }
     }
     float sa = da[w] + __shfl_xor(da[w], 32);
     float sb = db[w] + __shfl_xor(db[w], 32);
@@ -695,7 +716,7 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K
                      (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_bwd_k_gather_kernel<PREC>), dim3(grid), dim3(TG), 0, st, d, (const char*)Q,
+  hipLaunchKernelGGL((attn_bwd_k_gather_kernel<PREC>), dim3(grid * GSPLIT), dim3(TG), 0, st, d, (const char*)Q,
                      (const char*)Qt, (const char*)K, (const char*)V, key_a, key_b, (const char*)table_pair,
                      (const char*)dO, (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
   return (int)hipGetLastError();

@@ -107,8 +107,11 @@ class SCADeformableAttention(nn.Module):
             pos = pos.gather(3, key_order[None, :, None, :, None].expand(B, V, g, N, 2))
         pos = pos.reshape(B * V * g, N, 2)
         xs = ops.sample_features(x.reshape(B * V, C, Hi, Wi), pos, g)            # (B*V, N, C)
-        k = F.linear(xs, self.proj_k.weight.flatten(1), self.proj_k.bias)
-        v = F.linear(xs, self.proj_v.weight.flatten(1), self.proj_v.bias)
+        # proj_k and proj_v as ONE GEMM over the sampled features (same arithmetic per output column; the features are
+        # read once instead of twice)
+        kv = F.linear(xs, torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0),
+                      torch.cat((self.proj_k.bias, self.proj_v.bias), 0))
+        k, v = kv.split(kv.shape[-1] // 2, dim=-1)
         o = ops.attention_core(query, k, v, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
                                precision=self.precision)                         # (B*V, S*S, C)
         o = o.reshape(B, V, S * S, C).permute(0, 2, 1, 3).reshape(B, S * S, V * C)

@@ -87,8 +87,11 @@ class TSADeformableAttention(nn.Module):
         B, C, H, W = x.shape
         pos = self.key_positions(query)
         xs = ops.sample_features(x, pos, self.n_groups)                                  # (B, N, C)
-        k = F.linear(xs, self.proj_k.weight.flatten(1), self.proj_k.bias)
-        v = F.linear(xs, self.proj_v.weight.flatten(1), self.proj_v.bias)
+        # proj_k and proj_v as ONE GEMM over the sampled features (same arithmetic per output column; the features are
+        # read once instead of twice)
+        kv = F.linear(xs, torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0),
+                      torch.cat((self.proj_k.bias, self.proj_v.bias), 0))
+        k, v = kv.split(kv.shape[-1] // 2, dim=-1)
         o = ops.attention_core(query, k, v, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
                                views=1, precision=self.precision)                        # (B, H*W, C)
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)

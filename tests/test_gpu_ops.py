@@ -169,3 +169,46 @@ def test_recall_rank_matches_reference_golden():
         rank = ops.recall_rank(D).cpu().numpy()
         got = tuple(float((rank < i).mean() * 100.0) for i in (1, 5, 10))
         np.testing.assert_allclose(np.array(got), z[f"recall_{tag}"], atol=1e-9)
+
+
+def test_key_prep_workspace_matches_numpy():
+    """bevr_attn_key_prep through the C ABI: per-key (row offset, fraction, clamped column, row relative to the half's
+    first row) and the tap box of every 32-key half of a step, against a numpy restatement of the header's contract
+    (clamp a to [-(Sp+1), Ht+1], b to [-(Wt/2+2), Wt+1]; padded keys excluded from the boxes)."""
+    import ctypes as C
+    S, Wt, N, P = 10, 99, 150, 3
+    geom = ops.AttnGeom(n_prob=P, q_div=1, heads=2, groups=1, S=S, N=N, Wt=Wt, precision=_lib.PREC_BF16)
+    d = geom.desc()
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    a = (torch.rand(P, geom.Np, generator=g) * 3 - 1) * 2 * S          # exercises both clamps
+    b = (torch.rand(P, geom.Np, generator=g) * 3 - 1) * Wt
+    nbytes = L.bevr_attn_key_ws_bytes(C.byref(d))
+    assert nbytes == P * geom.Np * 16 + P * (geom.Np // 32) * 16
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    ad, bd = a.to(DEV).contiguous(), b.to(DEV).contiguous()
+    rc = L.bevr_attn_key_prep(C.byref(d), C.c_void_p(ad.data_ptr()), C.c_void_p(bd.data_ptr()),
+                              C.c_void_p(ws.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    raw = ws.cpu().numpy()
+    kw = raw[:P * geom.Np * 16].view(np.int32).reshape(P, geom.Np, 4)
+    box = raw[P * geom.Np * 16:].view(np.int32).reshape(P, geom.Np // 32, 4)
+    an = np.clip(a.numpy(), -(geom.Sp + 1), geom.Ht + 1)
+    bn = np.clip(b.numpy(), -(Wt // 2 + 2), Wt + 1)
+    A = np.floor(an).astype(np.int64)
+    live = np.arange(geom.Np)[None, :] < N
+    np.testing.assert_array_equal(kw[..., 0], ((A + geom.y_off) + geom.x_off * geom.Hp) * 8)
+    np.testing.assert_allclose(kw[..., 1].view(np.float32), (an - A).astype(np.float32), atol=1e-6)
+    for p in range(P):
+        for h in range(geom.Np // 32):
+            sl = slice(32 * h, 32 * h + 32)
+            lv = live[0, sl]
+            if not lv.any():
+                assert box[p, h, 1] < box[p, h, 0]            # empty half: amax < amin
+                continue
+            amin, amax = A[p, sl][lv].min(), A[p, sl][lv].max()
+            assert (box[p, h, 0], box[p, h, 1]) == (amin, amax)
+            np.testing.assert_allclose(box[p, h, 2:].view(np.float32), [bn[p, sl][lv].min(), bn[p, sl][lv].max()], rtol=1e-6)
+            np.testing.assert_array_equal(kw[p, sl, 3][lv], (A[p, sl][lv] - amin) * 8)
+            np.testing.assert_allclose(kw[p, sl, 2].view(np.float32)[lv], bn[p, sl][lv].astype(np.float32), rtol=1e-6)

@@ -25,7 +25,7 @@ SYMBOLS = [
     "bevr_abi_version", "bevr_strerror", "bevr_attn_table_dims", "bevr_attn_key_ws_bytes", "bevr_attn_key_prep",
     "bevr_attn_fwd", "bevr_attn_bwd_q",
     "bevr_attn_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_project_bev_grid", "bevr_corr_fwd",
-    "bevr_corr_bwd", "bevr_recall_rank",
+    "bevr_corr_bwd", "bevr_recall_rank", "bevr_dwconv_fwd", "bevr_dwconv_bwd_w",
 ]
 
 
@@ -86,6 +86,8 @@ def lib() -> C.CDLL:
         L.bevr_corr_fwd.argtypes = [fp] * 5 + [ip] * 4 + [vp]
         L.bevr_corr_bwd.argtypes = [fp] * 8 + [ip] * 4 + [vp]
         L.bevr_recall_rank.argtypes = [fp, vp, ip, vp]
+        L.bevr_dwconv_fwd.argtypes = [fp, fp, fp, fp] + [ip] * 7 + [vp]
+        L.bevr_dwconv_bwd_w.argtypes = [fp, fp, fp, fp] + [ip] * 6 + [vp]
         for name in SYMBOLS:
             fn = getattr(L, name)
             if name == "bevr_attn_key_ws_bytes":

@@ -5,41 +5,29 @@ import torch.nn.functional as F
 from torch import nn
 
 
-def depthwise_conv2d(x, conv: nn.Conv2d):
-    """A depthwise (groups == channels, one filter per channel) stride-1 `nn.Conv2d` evaluated as k*k shifted
-    multiply-adds.  Same arithmetic as the module; MIOpen runs the fp32 depthwise weight gradient through its
-    naive reference kernel (59 ms per call at 200x200, C = 256), while these are plain bandwidth-bound
-    elementwise passes.  Other configurations fall through to the module."""
+def _dw_ok(x, conv: nn.Conv2d) -> bool:
     k = conv.kernel_size[0]
-    if (conv.groups != conv.in_channels or conv.out_channels != conv.in_channels or conv.stride != (1, 1)
-            or conv.kernel_size != (k, k) or conv.padding != (k // 2, k // 2) or conv.dilation != (1, 1) or k % 2 == 0):
+    return (conv.groups == conv.in_channels == conv.out_channels and conv.stride == (1, 1)
+            and conv.kernel_size == (k, k) and conv.padding == (k // 2, k // 2) and conv.dilation == (1, 1)
+            and k % 2 == 1 and k <= 5 and x.dtype == torch.float32)
+
+
+def depthwise_conv2d(x, conv: nn.Conv2d):
+    """A depthwise (groups == channels, one filter per channel) stride-1 'same' `nn.Conv2d` on an NCHW tensor through
+    the HIP kernel (csrc/dwconv.hip): MIOpen runs the fp32 depthwise weight gradient through its naive reference
+    kernel (59 ms per call at 200x200, C = 256).  Other configurations fall through to the module."""
+    if not x.is_cuda or not _dw_ok(x, conv):   # glue layer: host tensors and odd configurations stay on the stock module
         return conv(x)
-    H, W = x.shape[-2:]
-    xp = F.pad(x, (k // 2,) * 4)
-    w = conv.weight
-    out = None
-    for dy in range(k):
-        for dx in range(k):
-            term = xp[..., dy:dy + H, dx:dx + W] * w[:, 0, dy, dx].view(1, -1, 1, 1)
-            out = term if out is None else out + term
-    if conv.bias is not None:
-        out = out + conv.bias.view(1, -1, 1, 1)
-    return out
+    from .. import ops
+    return ops.depthwise_conv(x, conv.weight, conv.bias, nhwc=False)
 
 
 def depthwise_conv2d_nhwc(x, conv: nn.Conv2d):
     """depthwise_conv2d for a channels-last (B, H, W, C) tensor (stride 1, odd kernel, 'same' padding)."""
-    k = conv.kernel_size[0]
-    assert conv.groups == conv.in_channels == conv.out_channels and conv.stride == (1, 1) and k % 2 == 1
-    H, W = x.shape[1:3]
-    xp = F.pad(x, (0, 0, k // 2, k // 2, k // 2, k // 2))
-    w = conv.weight
-    out = None
-    for dy in range(k):
-        for dx in range(k):
-            term = xp[:, dy:dy + H, dx:dx + W, :] * w[:, 0, dy, dx]
-            out = term if out is None else out + term
-    return out if conv.bias is None else out + conv.bias
+    if not x.is_cuda or not _dw_ok(x, conv):
+        return conv(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    from .. import ops
+    return ops.depthwise_conv(x, conv.weight, conv.bias, nhwc=True)
 
 
 def pointwise_conv_nhwc(x, conv: nn.Conv2d):

@@ -422,3 +422,51 @@ def recall_rank(D: torch.Tensor) -> torch.Tensor:
     rank = torch.empty(n, device=D.device, dtype=torch.int32)
     _lib.check(_lib.lib().bevr_recall_rank(_ptr(D), _ptr(rank), n, _stream()), "bevr_recall_rank")
     return rank
+
+
+# --------------------------------------------------------------------------------------------------
+# depthwise k x k convolution of the EncoderLayer glue (csrc/dwconv.hip)
+# --------------------------------------------------------------------------------------------------
+class _DwConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, nhwc: bool):
+        _require_gpu(x, weight)
+        L = _lib.lib()
+        x = x.contiguous()
+        w = weight.contiguous()
+        if nhwc:
+            B, H, W, Cc = x.shape
+        else:
+            B, Cc, H, W = x.shape
+        k = w.shape[-1]
+        y = torch.empty_like(x)
+        _lib.check(L.bevr_dwconv_fwd(_ptr(x), _ptr(w), _ptr(bias.contiguous()) if bias is not None else None, _ptr(y),
+                                     B, H, W, Cc, k, int(nhwc), 0, _stream()), "bevr_dwconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.meta = (B, H, W, Cc, k, nhwc, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, H, W, Cc, k, nhwc, has_bias = ctx.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.bevr_dwconv_fwd(_ptr(dy), _ptr(w), None, _ptr(dx), B, H, W, Cc, k, int(nhwc), 1, _stream()),
+                       "bevr_dwconv_fwd(flip)")
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw = torch.zeros_like(w)
+            db = torch.zeros(Cc, device=x.device, dtype=x.dtype) if has_bias else None
+            _lib.check(L.bevr_dwconv_bwd_w(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db) if db is not None else None,
+                                           B, H, W, Cc, k, int(nhwc), _stream()), "bevr_dwconv_bwd_w")
+        return dx, dw, db, None
+
+
+def depthwise_conv(x: torch.Tensor, weight: torch.Tensor, bias, nhwc: bool) -> torch.Tensor:
+    """Depthwise k x k (k odd <= 5), stride 1, 'same' padding.  x (B,H,W,C) if nhwc else (B,C,H,W) float32;
+    weight (C,1,k,k) as in nn.Conv2d(groups=C); bias (C,) or None."""
+    return _DwConv.apply(x, weight, bias, nhwc)
+

@@ -19,6 +19,7 @@
  *   bevr_sample_fwd/bwd     F.grid_sample at model/SCA_deform_attn.py:290-301, model/TSA_deform_attn.py:210-217
  *   bevr_attn_fwd/bwd_*     model/SCA_deform_attn.py:331-413, model/TSA_deform_attn.py:245-333
  *                           (QK^T*scale + bilinear RPE bias + softmax + PV, never materialised)
+ *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
  *   bevr_corr_fwd/bwd       train.py:554 (2 - 2 cam map^T) and the pairwise distance inside
  *                           loss/contrastive_loss.py:10-19 / loss/lift_loss.py:13-22
  */
@@ -170,6 +171,19 @@ int bevr_corr_bwd(const float* cam, const float* map, const float* D, const floa
                   int n, int m, int E, int normalize, void* stream);
 /* Rank of the diagonal within its column (train.py:559-563): rank[k] = #{ i : D[i][k] < D[k][k] }. */
 int bevr_recall_rank(const float* D, int32_t* rank, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Depthwise k x k convolution, one filter per channel, stride 1, zero "same" padding, k odd and <= 5: the local
+ * perception units and the MLP's 3x3 of the reference's EncoderLayer (model/encoder.py:363-411,
+ * model/model_utils.py:6-35) and TSA's offset head (model/TSA_deform_attn.py:54-68).
+ *   x, y  [B][H][W][C] (nhwc = 1) or [B][C][H][W] (nhwc = 0) float      w [C][k][k] float      bias [C] or NULL
+ *   flip = 1 correlates with the flipped filter: the input gradient is bevr_dwconv_fwd(dy, w, NULL, dx, ..., flip = 1).
+ * bevr_dwconv_bwd_w ACCUMULATES dw [C][k][k] and dbias [C] (dbias may be NULL); the caller zeroes them.
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_dwconv_fwd(const float* x, const float* w, const float* bias, float* y,
+                    int B, int H, int W, int C, int k, int nhwc, int flip, void* stream);
+int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
+                      int B, int H, int W, int C, int k, int nhwc, void* stream);
 
 #ifdef __cplusplus
 }

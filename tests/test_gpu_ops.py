@@ -212,3 +212,30 @@ def test_key_prep_workspace_matches_numpy():
             np.testing.assert_allclose(box[p, h, 2:].view(np.float32), [bn[p, sl][lv].min(), bn[p, sl][lv].max()], rtol=1e-6)
             np.testing.assert_array_equal(kw[p, sl, 3][lv], (A[p, sl][lv] - amin) * 8)
             np.testing.assert_allclose(kw[p, sl, 2].view(np.float32)[lv], bn[p, sl][lv].astype(np.float32), rtol=1e-6)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("shape", [(2, 8, 9, 7, 3), (1, 64, 40, 40, 3), (2, 5, 6, 11, 5), (1, 3, 4, 4, 1)])
+def test_depthwise_conv_matches_torch(shape, nhwc):
+    """bevr_dwconv_fwd / bwd_w (the EncoderLayer glue's depthwise convolutions) against F.conv2d(groups=C):
+    forward, input gradient, weight and bias gradients; both layouts; ragged sizes; k = 1, 3, 5."""
+    B, Cc, H, W, k = shape
+    g = torch.Generator().manual_seed(B * 100 + Cc + k)
+    x = torch.randn(B, Cc, H, W, generator=g)
+    w = torch.randn(Cc, 1, k, k, generator=g) * 0.3
+    b = torch.randn(Cc, generator=g)
+    cot = torch.randn(B, Cc, H, W, generator=g)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    want = F.conv2d(xr, wr, br, padding=k // 2, groups=Cc)
+    want.backward(cot)
+    xg, wg, bg = (t.clone().to(DEV).requires_grad_(True) for t in (x, w, b))
+    if nhwc:
+        got = ops.depthwise_conv(xg.permute(0, 2, 3, 1).contiguous(), wg, bg, nhwc=True).permute(0, 3, 1, 2)
+    else:
+        got = ops.depthwise_conv(xg, wg, bg, nhwc=False)
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=2e-4, atol=2e-4)

@@ -5,12 +5,12 @@ sys.path.insert(0, ROOT)
 sys.argv = ["bench.py", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
 import bench
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     bench.main()
-ka = prof.key_averages()
+ka = prof.key_averages(group_by_input_shape=True)
 rows = sorted(ka, key=lambda e: -e.self_device_time_total)
 tot = 0.0
-for e in rows[:45]:
+for e in rows[:60]:
     if "attn" in e.key or "Memcpy" in e.key:
         continue
-    print(f"{e.self_device_time_total/2e3:9.2f} ms/step {e.count//2:6d} calls/step  {e.key[:100]}")
+    print(f"{e.self_device_time_total/2e3:9.2f} ms/step {e.count//2:6d} calls/step  {e.key[:60]}  {str(e.input_shapes)[:110]}")

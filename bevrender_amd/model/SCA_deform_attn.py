@@ -66,7 +66,9 @@ class SCADeformableAttention(nn.Module):
         Returns (B*g, S, S, D)."""
         dw, norm, act, pw = head[0], head[1], head[2], head[3]
         mult = dw.out_channels // dw.in_channels
-        y = qg.permute(0, 2, 3, 1).repeat_interleave(mult, dim=-1) * dw.weight.flatten() + dw.bias
+        # depthwise 1x1 with channel multiplier: out[c * mult + m] = q[c] * w[c * mult + m] + b[c * mult + m], one pass
+        qh = qg.permute(0, 2, 3, 1).unsqueeze(-1)                                 # (B*g, S, S, C, 1) view
+        y = torch.addcmul(dw.bias.view(-1, mult), qh, dw.weight.view(-1, mult)).flatten(-2)
         y = F.layer_norm(y, norm.norm.normalized_shape, norm.norm.weight, norm.norm.bias, norm.norm.eps)
         return F.linear(act(y), pw.weight.flatten(1), pw.bias)
 

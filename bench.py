@@ -195,10 +195,14 @@ def main():
 
     from bevrender_amd import parallel
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    rank, world, local_rank = parallel.init_distributed("nccl")
+    # BEVR_BENCH_REHEARSAL=1: every rank on cuda:0 over gloo -- exercises the multi-rank control flow (DDP wrap,
+    # barriers, max-over-ranks timing, rank-0 report) on a one-GPU box.  Never a measurement.
+    rehearsal = os.environ.get("BEVR_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    rank, world, local_rank = parallel.init_distributed("gloo" if rehearsal else "nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 with torch.distributed.run)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
 
     from bevrender_amd import _lib, ops
     S, C, heads, D, V, L, B = args.bev, 64, 2, 5, 6, 2, args.batch
@@ -207,7 +211,7 @@ def main():
     torch.manual_seed(15213 + rank)
     model = LiftBlock(S, C, heads, D, V, L, img_w, img_h, args.precision, dev).to(dev)
     # identical initial weights on every rank (DDP broadcasts rank 0's); one flat 25 MB bucket holds all grads
-    net = parallel.wrap_data_parallel(model, local_rank)
+    net = parallel.wrap_data_parallel(model, dev_index)
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
 
     gen = torch.Generator(device=dev).manual_seed(15213 + rank)
@@ -270,14 +274,15 @@ def main():
             "metric": "samples/sec fwd+bwd, 6-cam 256x704 BEV-lift+corr",
             "value": round(total_samples / dt, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearsal else ""),
             "config": {"workload": f"cfg2+corr: 6-cam 256x704 features (64x64x176), {S}x{S} BEV, C=64 h=2 D=5, L=2 "
                                    f"encoder layers (TSA+SCA), T=2 (1 no-grad history frame + 1 fwd+bwd), "
                                    f"contrastive correlation head, AdamW; backbone/render CNN excluded",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world >= 1:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

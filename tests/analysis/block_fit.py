@@ -1,6 +1,6 @@
 """How many 256-key blocks of the bench SCA geometry fit the bwd_k LDS ring (host-side estimate, static keys)."""
 import os, sys, math, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bench import ring_rig
 from oracle import bevrender_oracle as orc

@@ -1,6 +1,6 @@
 """Fraction of 64-key steps (and of their 32-key halves) whose tap box fits the query-stationary LDS windows (static keys)."""
 import os, sys, math, numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from bench import ring_rig
 from oracle import bevrender_oracle as orc

@@ -20,8 +20,10 @@ def _pair_dist(cmr, mp):
 
 
 def _avg_nonzero(t):
+    """AvgNonZeroReducer: mean over the entries > 0, 0 if there is none -- as a masked sum, without the host
+    synchronisation a data-dependent index would cost inside the training step."""
     nz = t > 0
-    return t[nz].mean() if bool(nz.any()) else t.sum() * 0
+    return (t * nz).sum() / nz.sum().clamp_min(1)
 
 
 class ContrastiveLoss(nn.Module):

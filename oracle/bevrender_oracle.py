@@ -13,7 +13,9 @@ the reference's own modules (tests/golden/make_golden.py -> tests/golden/*.npz;
 tests/test_oracle_golden.py).  The retrieval losses (section 5) restate the
 published algorithm of the un-vendored, un-pinned dependency
 `pytorch_metric_learning`; the reference holds no test or fixture for them:
-PARITY UNPINNED for those three functions only.
+PARITY UNPINNED for those four functions only (the three retrieval losses and their
+shared pairwise distance).  The eval-mode ego-motion warp (section 6) restates
+`torchvision.transforms.functional.affine` (absent here): PARITY UNPINNED as well.
 
 All functions are differentiable torch code (no in-place on inputs), so the
 gradients the kernels must reproduce come from autograd on this file.
@@ -62,26 +64,87 @@ def _offset_net(qg: Tensor, p: Dict[str, Tensor], prefix: str, stride: int, pad:
 
 
 def attention_core(q: Tensor, k: Tensor, v: Tensor, pos: Tensor, rpe_table: Tensor,
-                   Hq: int, Wq: int, n_groups: int, scale: float) -> Tensor:
+                   Hq: int, Wq: int, n_groups: int, scale: float, rows: Optional[Tensor] = None) -> Tensor:
     """Dense softmax attention with bilinear relative-position bias (materialised, as the reference does).
 
     q (B*h, c, M) raw query; k, v (B*h, c, N); pos (B*g, N, 2) key positions (y, x) in [-1,1] units;
     rpe_table (h, Ht, Wt).  Returns (B*h, c, M).
     model/SCA_deform_attn.py:331-413, model/TSA_deform_attn.py:245-333.
+
+    rows (long tensor of query indices m = i*Wq + j, optional): attention rows are independent of each other, so
+    the same arithmetic restricted to a subset of the queries is the reference's result for those queries; the
+    return value is then (B*h, c, len(rows)).  This is how sizes whose (M x N) tensors do not fit in host memory
+    (S = 200: 4e9 entries per head) are checked against the materialised formulation.
     """
     Bh, c, M = q.shape
     h = rpe_table.shape[0]
     B = Bh // h
     g = n_groups
     N = k.shape[-1]
-    attn = torch.einsum("bcm,bcn->bmn", q, k) * scale
     q_grid = normalized_grid(Hq, Wq, q.dtype, q.device).reshape(1, M, 2)
+    if rows is not None:
+        q = q[:, :, rows]
+        q_grid = q_grid[:, rows]
+        M = q.shape[-1]
+    attn = torch.einsum("bcm,bcn->bmn", q, k) * scale
     disp = (q_grid.unsqueeze(2) - pos.reshape(B * g, 1, N, 2)) * 0.5          # (B*g, M, N, 2) (y,x)
     table = rpe_table[None].expand(B, -1, -1, -1).reshape(B * g, h // g, *rpe_table.shape[-2:])
     bias = F.grid_sample(table, disp[..., (1, 0)], mode="bilinear", align_corners=True)  # (B*g, h/g, M, N)
     attn = attn + bias.reshape(Bh, M, N)
     attn = F.softmax(attn, dim=2)
     return torch.einsum("bmn,bcn->bcm", attn, v)
+
+
+def attention_core_streaming(q: Tensor, k: Tensor, v: Tensor, pos: Tensor, rpe_table: Tensor,
+                             Hq: int, Wq: int, n_groups: int, scale: float, tile: int = 4096) -> Tensor:
+    """The same function as attention_core, forward only, in the streaming form the kernels use (the algorithmic
+    twin of csrc/attn_fwd.hip): keys are visited `tile` at a time with an online softmax, and the bias is the
+    explicit 4-tap bilinear lookup at table coordinates ty = i + a_n, tx = j*rx + b_n
+    (a_n = (1 - py_n)(Hq-1)/2, b_n = (1 - px_n)(Wt-1)/4, rx = (Wt-1)/(2(Wq-1))): algebraically
+    grid_sample(align_corners=True, zeros padding) of (q_grid - pos)/2, model/SCA_deform_attn.py:365-389.
+    Never holds more than (B*h, M, tile) values, so it runs where attention_core cannot."""
+    Bh, c, M = q.shape
+    h, Ht, Wt = rpe_table.shape
+    B, g, N = Bh // h, n_groups, k.shape[-1]
+    hpg = h // g
+    ii = torch.arange(Hq, dtype=q.dtype).repeat_interleave(Wq)              # BEV row of query m = i*Wq + j
+    jj = torch.arange(Wq, dtype=q.dtype).repeat(Hq)
+    rx = (Wt - 1.0) / (2.0 * (Wq - 1.0))
+    ry = (Ht - 1.0) / (2.0 * (Hq - 1.0))                                     # 1 for the reference's Ht = 2 Hq - 1
+    m_run = torch.full((Bh, M), -float("inf"), dtype=q.dtype)
+    l_run = torch.zeros(Bh, M, dtype=q.dtype)
+    o_run = torch.zeros(Bh, c, M, dtype=q.dtype)
+    tpad = F.pad(rpe_table, (1, 1, 1, 1))                                    # zero ring: out-of-range taps read 0
+    for n0 in range(0, N, tile):
+        n1 = min(N, n0 + tile)
+        kk, vv = k[:, :, n0:n1], v[:, :, n0:n1]
+        s = torch.einsum("bcm,bcn->bmn", q, kk) * scale
+        p_ = pos.reshape(B, g, N, 2)[:, :, n0:n1]
+        a = (1.0 - p_[..., 0]) * ((Ht - 1.0) / 4.0)                          # (B, g, n)
+        b = (1.0 - p_[..., 1]) * ((Wt - 1.0) / 4.0)
+        ty = (ii * ry)[None, None, :, None] + a[:, :, None, :]               # (B, g, M, n)
+        tx = (jj * rx)[None, None, :, None] + b[:, :, None, :]
+        y0, x0 = torch.floor(ty), torch.floor(tx)
+        fy, fx = ty - y0, tx - x0
+        y0 = y0.long().clamp(-1, Ht - 1) + 1                                  # index into the padded table
+        x0 = x0.long().clamp(-1, Wt - 1) + 1
+        inside = ((ty > -1) & (ty < Ht) & (tx > -1) & (tx < Wt)).to(q.dtype)
+        bias = torch.empty(B, g, hpg, M, n1 - n0, dtype=q.dtype)
+        for hh in range(hpg):
+            for gi in range(g):
+                t = tpad[gi * hpg + hh]
+                yy, xx = y0[:, gi], x0[:, gi]
+                val = (t[yy, xx] * (1 - fy[:, gi]) * (1 - fx[:, gi]) + t[yy + 1, xx] * fy[:, gi] * (1 - fx[:, gi])
+                       + t[yy, xx + 1] * (1 - fy[:, gi]) * fx[:, gi] + t[yy + 1, xx + 1] * fy[:, gi] * fx[:, gi])
+                bias[:, gi, hh] = val * inside[:, gi]
+        s = s + bias.reshape(Bh, M, n1 - n0)
+        m_new = torch.maximum(m_run, s.max(dim=2).values)
+        alpha = torch.exp(m_run - m_new)
+        pexp = torch.exp(s - m_new[..., None])
+        l_run = l_run * alpha + pexp.sum(2)
+        o_run = o_run * alpha[:, None, :] + torch.einsum("bmn,bcn->bcm", pexp, vv)
+        m_run = m_new
+    return o_run / l_run[:, None, :]
 
 
 # --------------------------------------------------------------------------- #
@@ -338,6 +401,44 @@ def lifted_structure_loss(cam: Tensor, mp: Tensor, neg_margin: float = 1.0, pos_
             negs = torch.cat(((neg_margin - d[i])[~same[i]], (neg_margin - d[j])[~same[j]]))
             losses.append(F.relu(torch.logsumexp(negs, 0) + d[i, j] - pos_margin) ** 2 / 2.0)
     return torch.stack(losses).mean()
+
+
+def triplet_margin_loss(cam: Tensor, mp: Tensor, miner_margin: float = 0.2, loss_margin: float = 0.05,
+                        reducer_high: float = 0.3) -> Tensor:
+    """loss/triplet_loss_metric.py:8-28 -> pytorch_metric_learning (un-vendored, un-pinned: PARITY UNPINNED):
+      miner  TripletMarginMiner(margin=0.2, "semihard") on LpDistance(normalize_embeddings=True): every triplet
+             (a, p, n) with label[a] == label[p], a != p, label[n] != label[a] and 0 < d_an - d_ap <= margin (no grad);
+      loss   TripletMarginLoss(margin=0.05, distance=CosineSimilarity()): relu(cos_an - cos_ap + margin) per mined
+             triplet (an inverted distance: larger = closer);
+      reduce ThresholdReducer(high=0.3): mean over the triplet losses < high (zeros included), 0 if none passes;
+      plus   LpRegularizer() (p=2) on the raw embeddings with the default weight 1 and MeanReducer: mean ||e||_2.
+    Written as the triple loop the library's index lists amount to."""
+    B = cam.shape[0]
+    emb = torch.cat((cam, mp), 0)
+    lab = torch.cat((torch.arange(B), torch.arange(B)))
+    with torch.no_grad():
+        d = _pairwise_lp_normalized(emb)
+    e = F.normalize(emb, p=2, dim=1)
+    cos = e @ e.t()
+    losses = []
+    for a in range(2 * B):
+        for p_ in range(2 * B):
+            if p_ == a or lab[p_] != lab[a]:
+                continue
+            for n in range(2 * B):
+                if lab[n] == lab[a]:
+                    continue
+                m = (d[a, n] - d[a, p_]).item()
+                if 0 < m <= miner_margin:
+                    losses.append(F.relu(cos[a, n] - cos[a, p_] + loss_margin))
+    reg = emb.norm(p=2, dim=1).mean()
+    if not losses:
+        return reg + emb.sum() * 0
+    losses = torch.stack(losses)
+    keep = losses < reducer_high
+    if int(keep.sum()) < 1:
+        return reg + emb.sum() * 0
+    return losses[keep].mean() + reg
 
 
 def pairwise_corr(cam: Tensor, mp: Tensor) -> Tensor:

@@ -19,6 +19,8 @@ Fixtures (fp32, seeded):
   G2 sca_*.npz      SCADeformableAttention   model/SCA_deform_attn.py:180-421 (n_views=1)
   G3 proj_*.npz     sample_3d_points + bev_grid_to_camera  model/SCA.py:112-162, model/bev_cmr_proj.py:61-124
   G4 enclayer.npz   EncoderLayer fwd+bwd (train mode, drop 0)  model/encoder.py:339-411
+  G4b enclayer_s56.npz  the same at BEV side 56, C=64, D=5 (M=3136, N_sca=7840: the largest side the reference's
+                    materialised tensors fit in this container); weights/inputs are seeded, only sampled values stored
   G5 full_bevrender.npz  full BEVRender fwd+bwd, T=2, S=28 (separate script: make_golden_full.py)  model/bevrender.py:14-221
   G7 recall.npz     Trainer.get_recall        train.py:551-572
 """
@@ -96,6 +98,23 @@ def randomize_(module, seed):
             else:
                 fan_in = p[0].numel()
                 p.copy_(torch.randn(p.shape, generator=g) / fan_in ** 0.5)
+
+
+def randomize_by_name_(module, seed):
+    """randomize_ with one generator per parameter, seeded from the parameter's NAME: independent of the order in
+    which a module registers its parameters, so this repo's module and the reference's get identical weights."""
+    import zlib
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            g = torch.Generator().manual_seed(seed * 1000003 + zlib.crc32(n.encode()))
+            if n.endswith("rpe_table"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            elif "norm" in n and n.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif p.ndim <= 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) / p[0].numel() ** 0.5)
 
 
 def run_module(mod, call, inputs, cot_seed):
@@ -257,6 +276,66 @@ def gen_enclayer():
     save("enclayer.npz", rec)
 
 
+ENC56 = dict(B=1, C=64, S=56, D=5, h=2, Hi=32, Wi=32, bound={"X": 20, "Y": 10, "Z": 2}, wseed=356, iseed=357,
+             cseed=358)
+
+
+def enclayer_s56_inputs():
+    """Seeded inputs of G4b (shared with tests/test_gpu_fullsize.py: the CPU generator is deterministic for a
+    given torch build, and the GPU box runs the same image)."""
+    c = ENC56
+    g = torch.Generator().manual_seed(c["iseed"])
+    bev_query = torch.randn(c["B"], c["C"], c["S"], c["S"], generator=g)
+    prev_bev = torch.randn(c["B"], c["C"], c["S"], c["S"], generator=g)
+    img_feat = torch.randn(c["B"], c["C"], c["Hi"], c["Wi"], generator=g)
+    cot = torch.randn(c["B"], c["C"], c["S"], c["S"], generator=torch.Generator().manual_seed(c["cseed"]))
+    return bev_query, prev_bev, img_feat, cot
+
+
+def sample_idx(n, k, seed):
+    return torch.randperm(n, generator=torch.Generator().manual_seed(seed))[:k]
+
+
+def gen_enclayer_s56():
+    from model.encoder import EncoderLayer
+    from model.bev_cmr_proj import BEV2CameraProjector
+
+    c = ENC56
+    T, K = make_rig("front1")
+    proj = BEV2CameraProjector(imu_to_rgb={0: T}, K={0: [k.copy() for k in K]}, vehicle_type_code=0, img_width=128,
+                               img_height=128, ori_img_width=128, ori_img_height=128, device="cpu")
+    torch.manual_seed(0)
+    layer = EncoderLayer(bev_bound=c["bound"], bev2cmr_projector=proj, n_views=1, bev_feat_shape=c["S"],
+                         bev_depth_dim=c["D"], z_shift=-1.0, dim_embed=c["C"], expansion=4, stage_idx=0, n_groups=1,
+                         n_heads=c["h"], stride=1, kernel_size=3, batch_size=c["B"], scale_offset_range=True,
+                         drop_path_rate=0.0)
+    randomize_by_name_(layer, c["wseed"])
+    layer.train()
+    bev_query, prev_bev, img_feat, cot = enclayer_s56_inputs()
+    ins = {"bev_query": bev_query, "prev_bev": prev_bev, "img_feat": img_feat}
+    for v in ins.values():
+        v.requires_grad_(True)
+    out = layer(bev_query, img_feat, prev_bev, torch.zeros(c["B"], 2, 3), torch.tensor(0), {}, False)[0]
+    layer.zero_grad()
+    out.backward(cot)
+    rec = {"out_sum": out.detach().double().sum(), "out_abs_sum": out.detach().double().abs().sum()}
+    oi = sample_idx(out.numel(), 2048, 1)
+    rec["out_idx"], rec["out_val"] = oi, out.detach().flatten()[oi]
+    names = []
+    for tag, items in (("grad_in.", ins.items()), ("grad_param.", layer.named_parameters())):
+        for n, t in items:
+            g = t.grad
+            if g is None:
+                continue
+            gi = sample_idx(g.numel(), min(g.numel(), 256), 2)
+            rec[tag + n + ".idx"], rec[tag + n + ".val"] = gi, g.flatten()[gi]
+            rec[tag + n + ".absmax"] = g.abs().max()
+            names.append(tag + n)
+    rec["names"] = np.array(names)
+    rec["n_state"] = len(layer.state_dict())
+    save("enclayer_s56.npz", rec)
+
+
 def gen_recall():
     """Trainer.get_recall (train.py:551-572) is a method that uses no `self` state."""
     import importlib.util
@@ -286,14 +365,19 @@ def gen_recall():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default=None, help="generate one fixture family only (e.g. enclayer_s56)")
     args = ap.parse_args()
     REF = args.ref
     sys.path.insert(0, REF)
     os.chdir(REF)  # reference modules do sys.path.append(Path.cwd())
     install_import_stubs()
     torch.set_num_threads(4)
+    if args.only:
+        globals()["gen_" + args.only]()
+        sys.exit(0)
     gen_tsa()
     gen_sca()
     gen_proj()
     gen_enclayer()
+    gen_enclayer_s56()
     gen_recall()

@@ -10,8 +10,10 @@ Workload (BASELINE.json configs[1] + the correlation head of configs[2]; SURVEY.
   (one process per GPU, gradient all-reduce over RCCL, weak scaling).  The image backbone and render CNN
   are outside the path (left to MIOpen) and are not run.
 
-Prints ONE JSON line (rank 0).  `python bench.py --gpus N --steps K --warmup W`; for N>1 launch with
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+Prints ONE JSON line (rank 0).  `python bench.py --gpus N --steps K --warmup W`.  For N > 1 either launch it under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU; RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* read from the environment) or run it bare: with no WORLD_SIZE in the environment it starts
+that launcher itself as a child process -- before anything touches the GPU -- and exits with the child's code.
 """
 import argparse
 import json
@@ -192,6 +194,19 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (importing torch does
+        # not), the ranks are fresh child processes (never an exec), rank 0's JSON line is the children's stdout.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=env).returncode)
 
     from bevrender_amd import parallel
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -15,7 +15,8 @@ import torch  # noqa: F401  -- must be imported BEFORE the library is loaded: to
 # "no ROCm-capable device".  With torch loaded first both share torch's runtime.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbevrender_hip.so")
+# BEVRENDER_LIB: another build of the same library (tests use it for the -DBEVR_DEBUG build with in-kernel traps)
+LIB_PATH = os.environ.get("BEVRENDER_LIB") or os.path.join(_HERE, "lib", "libbevrender_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 PREC_F32, PREC_BF16 = 0, 1

@@ -52,7 +52,7 @@ constexpr int NCOL = 8;   // query columns per workgroup (one per wave)
 
 template <int PREC> struct LdsQ {
   static constexpr int EB = Elem<PREC>::bytes;
-  static constexpr int CAP = PREC == BEVR_PREC_BF16 ? 64 : 48;   // region capacity (table columns)
+  static constexpr int CAP = PREC == BEVR_PREC_BF16 ? 52 : 48;   // region capacity (table columns)
   static constexpr int R_STRIDE = 32 * EB + 16;   // row-layout tiles (K, V): bytes per key row
   static constexpr int T_STRIDE = KT * EB + 16;   // transposed tile (Kt): bytes per channel row
   static constexpr int R_BYTES = KT * R_STRIDE;
@@ -66,7 +66,7 @@ template <int PREC> struct LdsQ {
   static constexpr int PCK = NWAVE * 32 * (PREC == BEVR_PREC_BF16 ? 16 : 32);   // per wave: one 32-key half at a time
   // bf16 mode: the tile's dO fragments live in LDS (fragment order, re-read every step) instead of 8 registers
   static constexpr int QDO = PREC == BEVR_PREC_BF16 ? NCOL * 2 * 64 * 16 : 16;     // per-wave (column, key) constants
-  static constexpr int ACCB = PREC == BEVR_PREC_BF16 ? 4 : 8;   // bytes per accumulation cell (see AccCell)
+  static constexpr int ACCB = 8;   // bytes per accumulation cell (see AccCell)
   static constexpr int TOTAL = BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK + QDO;
 };
 
@@ -78,14 +78,18 @@ __device__ __forceinline__ int cvt_rpi(float x) {
   return r;
 }
 
-// Fixed-point accumulation cell.  A cell of a workgroup's window receives, over the life of a region, at most
-// 2 BEV rows x 8 BEV columns = 16 queries' contributions, each query's bounded by max|dS| summed over keys with
-// softmax weights (sum <= 1): |cell sum| <= 16 * bound.
-//   f32 mode : 64-bit cells, unit = bound * 2^-30   (ds_add_u64; parity mode)
-//   bf16 mode: 32-bit cells, unit = bound * 2^-26   (ds_add_u32, ~4x cheaper on gfx950; 16 * 2^26 = 2^30 fits)
-// Conversion is round-to-nearest (truncation would bias the sum of many small same-sign contributions).
-template <int PREC> struct AccCell;
-template <> struct AccCell<BEVR_PREC_F32> {
+// Fixed-point accumulation cell: 64-bit in both precision modes.
+//   unit = bound * 2^-30, bound >= max |dS| over all pairs (handed in by the caller as grad_scale);
+//   one contribution |dS * w| <= bound converts to a 32-bit integer (v_cvt_rpi, round to nearest: truncation would
+//   bias the sum of many small same-sign contributions) and is sign-extended into the 64-bit cell, so a cell can
+//   take 2^33 contributions of the largest possible size before it wraps -- more than a launch has pairs per
+//   cell.  32-bit cells (tried in round 1 for the bf16 mode: ds_add_u32 is 4.4 clk, ds_add_u64 6.3) cannot hold
+//   both ends: a cell of the pinned-key box receives ~10^5 contributions per region, so a unit that is safe against
+//   wrap-around is ~bound * 2^-14, far above a typical contribution (P ~ 1/N): at S = 200 the table gradient came
+//   out 67 % wrong against the f32 mode (tests/test_gpu_fullsize.py).  Native LDS float atomics are no way out on
+//   gfx950 either: ds_add_f32 / ds_pk_add_bf16 retire ~3 clk per active LANE (193 clk per wave instruction;
+//   tools/micro/lds_bench.hip).
+template <int PREC> struct AccCell {
   typedef unsigned long long type;
   static constexpr float rescale = 1.0f;
   static __device__ __forceinline__ type from(float x) {
@@ -95,12 +99,6 @@ template <> struct AccCell<BEVR_PREC_F32> {
   static __device__ __forceinline__ float to_float(type v) {
     return (float)(int)(unsigned)(v >> 32) * 4294967296.0f + (float)(unsigned)v;
   }
-};
-template <> struct AccCell<BEVR_PREC_BF16> {
-  typedef unsigned type;
-  static constexpr float rescale = 0.0625f;   // 2^-4 of the 2^30-based scale handed in
-  static __device__ __forceinline__ type from(float x) { return (unsigned)cvt_rpi(x); }
-  static __device__ __forceinline__ float to_float(type v) { return (float)(int)v; }
 };
 
 template <int PREC>
@@ -272,6 +270,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
       accw[cell] = 0;
       if (do_flush && v != 0) {
         const int c = cell / WIN_PITCH, row = cell % WIN_PITCH;
+        BEVR_ASSERT(r.ax0 + c + d.x_off < d.Wp);   // only columns of the real padded table ever receive gradient
         const float f = Acc::to_float(v) * ginv;
         atomicAdd(dtb + (size_t)(r.ax0 + c + d.x_off) * Hq + (size_t)(i0 + r.ay0 + d.y_off + row), f);
       }
@@ -310,14 +309,16 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
       const StepBox sbh = kh ? sb1 : sb0;
       const WinInfo wi = wi_step.ok ? wi_step : make_wininfo(sbh, jrx_lo, jrx_hi, CAP);
       const bool use_win = wi.ok != 0;   // workgroup-uniform
+      BEVR_ASSERT_WG_UNIFORM((int)use_win * 65536 + wi.xlo * 131 + wi.amin * 7 + wi.ncols);
       if (use_win && !region_contains(rg, wi, CAP)) {
         if (kh) __syncthreads();   // mid-step move: every wave must be done with the first half's taps and adds
         flush_and_clear(rg, acc_live);
         rg = region_anchor(wi, d, i0, CAP);
         {   // fill the region: one wave-wide load per table column (lane = row)
           const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
+          BEVR_ASSERT(i0 + rg.ay0 + d.y_off >= 0 && i0 + rg.ay0 + d.y_off + WIN_PITCH <= d.Hp && rg.ax0 + d.x_off >= 0);
           for (int c = wave; c < CAP; c += NWAVE) {
-            f32x2 v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)(rg.ax0 + c + d.x_off) * d.Hp + y0) * 8);
+            const f32x2 v = region_entry(tbl, d, rg, c, y0);
             if constexpr (PREC == BEVR_PREC_BF16)
               *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
             else

@@ -184,12 +184,14 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
     // constants; otherwise the halves are windowed separately
     const WinInfo wi_step = make_wininfo(box_union(sb0, sb1), jrx_lo, jrx_hi, WIN_COLS);
     auto move_region = [&](const WinInfo& wi, bool mid_step) {
+      BEVR_ASSERT_WG_UNIFORM(wi.xlo * 131 + wi.amin * 7 + wi.ncols + (int)mid_step);
       if (mid_step) __syncthreads();   // every wave must be done with the first half's taps
       rg = region_anchor(wi, d, i0, WIN_COLS);
       // fill the region: one wave-wide load per table column (lane = row)
       const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
+      BEVR_ASSERT(i0 + rg.ay0 + d.y_off >= 0 && i0 + rg.ay0 + d.y_off + WIN_PITCH <= d.Hp && rg.ax0 + d.x_off >= 0);
       for (int c = wave; c < WIN_COLS; c += NWF) {
-        f32x2 v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)(rg.ax0 + c + d.x_off) * d.Hp + y0) * 8);
+        const f32x2 v = region_entry(tbl, d, rg, c, y0);
         if constexpr (PREC == BEVR_PREC_BF16)
           *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
         else

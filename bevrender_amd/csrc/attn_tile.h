@@ -135,12 +135,37 @@ __device__ __forceinline__ Region region_anchor(const WinInfo& wi, const bevr_at
   return rg;
 }
 
-// Cooperative fill of the whole region: one wave-wide 8-byte load per column (lane = row).
-__device__ __forceinline__ void load_region(char* win, const char* tbl, const bevr_attn_desc& d, const Region& rg,
-                                            int i0, int ncol_cap, int n_wave, int wave, int lane) {
-  const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
-  for (int c = wave; c < ncol_cap; c += n_wave) {
-    f32x2 v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)(rg.ax0 + c + d.x_off) * d.Hp + y0) * 8);
-    *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * 8) = v;
-  }
+// One (T[y], T[y+1]) entry of region column c for this lane's row, for the region fill (lane = row).
+// The region has a fixed capacity; the padded table of a SMALL problem (S = 8: Wp = 38) is narrower than that, and
+// region_anchor can then only clamp column 0 of the region to column 0 of the table: region columns past the
+// table's last column exist in LDS but must not be fetched -- no key's tap can point at them (taps are clamped into
+// the padded table), so they are filled with zeros.  Round 1 fetched them: up to 50 columns x Hp x 8 B past the end
+// of the last head's table, a read that faults only when the allocation happens to end at an unmapped page (the
+// "Fatal Python error: Aborted" of gpurun_out/gpu_tests_6.log, and again of r02_gpu_2.log: both in the S = 8 TSA
+// module test, the first launch with a 15-column table).
+__device__ __forceinline__ f32x2 region_entry(const char* tbl, const bevr_attn_desc& d, const Region& rg, int c, size_t y0) {
+  const int xc = rg.ax0 + c + d.x_off;   // padded table column: >= 0 by region_anchor
+  f32x2 v = {0.f, 0.f};
+  if (xc < d.Wp) v = *reinterpret_cast<const f32x2*>(tbl + ((size_t)xc * d.Hp + y0) * 8);
+  return v;
 }
+
+// Workgroup-uniformity contract of the query-stationary kernels: every __syncthreads() they execute conditionally
+// (region moves, mid-step moves) sits under predicates computed ONLY from kernel arguments, blockIdx and the
+// scalar-loaded StepBox records -- never from threadIdx, the wave's column or a key's data.  -DBEVR_DEBUG builds
+// check it: thread 0 publishes the predicate, every thread compares, a mismatch traps instead of hanging.
+#ifdef BEVR_DEBUG
+#define BEVR_ASSERT_WG_UNIFORM(EXPR_)                                               \
+  do {                                                                              \
+    __shared__ int bevr_dbg_u;                                                      \
+    __syncthreads();                                                                \
+    if (threadIdx.x == 0) bevr_dbg_u = (int)(EXPR_);                                \
+    __syncthreads();                                                                \
+    if (bevr_dbg_u != (int)(EXPR_)) __builtin_trap();                               \
+    __syncthreads();                                                                \
+  } while (0)
+#define BEVR_ASSERT(EXPR_) do { if (!(EXPR_)) __builtin_trap(); } while (0)
+#else
+#define BEVR_ASSERT_WG_UNIFORM(EXPR_) do { } while (0)
+#define BEVR_ASSERT(EXPR_) do { } while (0)
+#endif

@@ -53,13 +53,22 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
 
 
 def wrap_data_parallel(model: nn.Module, local_rank: int | None = None, bucket_cap_mb: int = 25) -> nn.Module:
-    """DistributedDataParallel with one flat bucket and no unused-parameter search; identity when world == 1."""
+    """DistributedDataParallel with one flat bucket and no unused-parameter search; identity when world == 1.
+
+    BatchNorm layers (image backbone, render decoder -- none on the hot path) keep the reference's semantics
+    (train.py:128-141 converts to SyncBatchNorm before wrapping): on GPU process groups they are converted to
+    SyncBatchNorm; where SyncBatchNorm cannot run (CPU / gloo tests) the running statistics are kept identical
+    across ranks by broadcasting buffers from rank 0 instead.  A module without BatchNorm has no buffers to sync."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
     on_gpu = next(model.parameters()).is_cuda
+    has_bn = any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in model.modules())
+    sync_bn = has_bn and on_gpu and dist.get_backend() == "nccl"
+    if sync_bn:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     return nn.parallel.DistributedDataParallel(
         model, device_ids=[local_rank] if on_gpu else None, bucket_cap_mb=bucket_cap_mb,
-        gradient_as_bucket_view=True, find_unused_parameters=False, broadcast_buffers=False)
+        gradient_as_bucket_view=True, find_unused_parameters=False, broadcast_buffers=has_bn and not sync_bn)
 
 
 def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:

@@ -85,6 +85,50 @@ def test_two_rank_gradients_equal_single_process():
         np.testing.assert_allclose(got[k], want[k], rtol=1e-5, atol=1e-7, err_msg=k)
 
 
+class TinyBN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 4, 1)
+        self.bn = nn.BatchNorm2d(4)
+
+    def forward(self, x):
+        return self.bn(self.conv(x)).square().mean()
+
+
+def _bn_worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    parallel.init_distributed("gloo")
+    torch.manual_seed(0)
+    net = parallel.wrap_data_parallel(TinyBN())
+    assert net.broadcast_buffers            # CPU ranks cannot run SyncBatchNorm: buffers follow rank 0 instead
+    for step in range(2):
+        x = torch.randn(4, 3, 5, 5, generator=torch.Generator().manual_seed(100 * rank + step))
+        net(x).backward()
+    net(torch.zeros(4, 3, 5, 5))            # a forward broadcasts rank 0's running statistics
+    out_q.put((rank, net.module.bn.running_mean.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_batchnorm_statistics_stay_identical_across_ranks():
+    """train.py:128-141 converts to SyncBatchNorm; the wrapper does that on GPU/RCCL groups and keeps the running
+    statistics identical by buffer broadcast where SyncBatchNorm cannot run (this CPU test)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(got[0], got[1])
+    assert np.abs(got[0]).max() > 0
+
+
 def test_shard_batch_and_world1_passthrough():
     t = torch.arange(8).reshape(8, 1)
     assert parallel.shard_batch(t, 1, 4).flatten().tolist() == [2, 3]

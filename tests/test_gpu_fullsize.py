@@ -61,10 +61,15 @@ def lift_problem(S, D, V, C, h, img_w, img_h, bound, seed, table_std=0.3):
     return dict(query=query, k=k, v=v, pos=pos, table=table, pinned=pinned)
 
 
-def oracle_rows(p, h, rows, cot, want_grads=True):
+def oracle_rows(p, h, rows, cot, want_grads=True, dtype=torch.float64):
     """oracle.attention_core on the query subset `rows`, one view at a time (each view is an independent softmax
-    problem sharing the query).  Returns out (V, R, C) and the gradients for the cotangent `cot` (V, R, C)."""
-    query, k, v, pos, table = (p[n].clone().requires_grad_(want_grads) for n in ("query", "k", "v", "pos", "table"))
+    problem sharing the query).  Returns out (V, R, C) and the gradients for the cotangent `cot` (V, R, C).
+    float64 by default: d(pos) is discontinuous where a table coordinate crosses an integer, and a float32 oracle
+    lands on either side of such a kink by its own rounding (see check_dpos)."""
+    query, k, v, pos, table = (p[n].clone().to(dtype).requires_grad_(want_grads)
+                               for n in ("query", "k", "v", "pos", "table"))
+    if cot is not None:
+        cot = cot.to(dtype)
     V, N, C = k.shape
     S = query.shape[-1]
     c = C // h
@@ -93,7 +98,44 @@ def pick_rows(S, R, seed):
 
 
 def rel_err(got, want):
-    return (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+    return (got.double() - want.double()).abs().max().item() / (want.abs().max().item() + 1e-30)
+
+
+def kink_distance(pos, S, Wt):
+    """Per key: how close a table coordinate of the key comes to an integer anywhere on the query grid.  The bias is
+    piecewise bilinear in (ty, tx) = (i + a_n, j rx + b_n): continuous, but its derivative with respect to the key
+    position jumps where ty or tx crosses an integer.  frac(ty) = frac(a_n) for every row i; tx is tested per column."""
+    pos = pos.double()
+    a = (1 - pos[..., 0]) * (S - 1) / 2
+    b = (1 - pos[..., 1]) * (Wt - 1) / 4
+    rx = (Wt - 1) / (2.0 * (S - 1))
+    dist = (a - a.round()).abs()
+    for j in range(S):
+        t = b + j * rx
+        dist = torch.minimum(dist, (t - t.round()).abs())
+    return dist
+
+
+def check_dpos(got, want, pos, S, Wt, lim, tag):
+    """d(pos) against the float64 oracle.  Keys whose table coordinate passes within float32 rounding of an integer
+    for some query column take the derivative of the neighbouring bilinear cell for that column (in this kernel as in
+    the float32 reference: at cfg1 the reference's own float32 and float64 evaluations differ by 6 % of the largest
+    entry on 4 of 6 250 keys, tools/debug_dpos.py).  So: (1) every key OUTSIDE the kink neighbourhood must meet the
+    limit; (2) keys that miss it must be few and must all be kink-adjacent; (3) the error in the 2-norm is small."""
+    got, want = got.double().cpu(), want.double()
+    err = (got - want).abs().amax(-1)
+    tol = lim * want.abs().max().item()
+    bad = err > tol
+    kd = kink_distance(pos, S, Wt)
+    n_bad, n = int(bad.sum()), bad.numel()
+    l2 = ((got - want).norm() / want.norm()).item()
+    worst_clean = (err[kd >= 2e-3].max().item() / want.abs().max().item()) if (kd >= 2e-3).any() else 0.0
+    print(f"[{tag}] d(pos): {n_bad} of {n} keys over {lim:.0e} x max (all within "
+          f"{kd[bad].max().item() if n_bad else 0:.1e} of a kink); worst key away from kinks {worst_clean:.3e}; "
+          f"2-norm rel err {l2:.3e}")
+    assert n_bad <= 0.02 * n, f"{tag}: {n_bad} of {n} keys differ"
+    assert n_bad == 0 or kd[bad].max().item() < 2e-3, f"{tag}: a key away from any kink differs"
+    assert l2 < 10 * lim, f"{tag}: 2-norm rel err {l2:.3e}"
 
 
 @pytest.fixture(scope="module")
@@ -135,10 +177,11 @@ def test_cfg2_attention_rows_and_gradients(cfg2, prec):
     print(f"\n[cfg2 {tag}] out rel err {e_out:.3e}")
     assert e_out < lim["out"], f"out: {e_out:.3e}"
     assert torch.isfinite(out).all()
-    for n in ("query", "k", "v", "pos", "table"):
+    for n in ("query", "k", "v", "table"):
         e = rel_err(ins[n].grad.cpu(), z["grads"][n])
         print(f"[cfg2 {tag}] grad {n:6s} rel err {e:.3e}  (max |want| {z['grads'][n].abs().max().item():.3e})")
         assert e < lim[n], f"grad {n}: {e:.3e}"
+    check_dpos(ins["pos"].grad, z["grads"]["pos"], p["pos"], S, p["table"].shape[-1], lim["pos"], f"cfg2 {tag}")
 
 
 def test_cfg2_bf16_agrees_with_f32_kernels_on_all_rows(cfg2):
@@ -192,7 +235,7 @@ def test_cfg1_bev50_full_rows(prec):
         k, v = torch.randn(B, N, C, generator=gen), torch.randn(B, N, C, generator=gen)
         table = torch.randn(h, 2 * S - 1, Wt, generator=gen) * 0.3
         cot = torch.randn(B, S * S, C, generator=gen)
-        cpu = [t.clone().requires_grad_(True) for t in (query, k, v, pos, table)]
+        cpu = [t.clone().double().requires_grad_(True) for t in (query, k, v, pos, table)]
         c = C // h
         outs = []
         for b in range(B):
@@ -200,7 +243,7 @@ def test_cfg1_bev50_full_rows(prec):
                                  cpu[2][b].reshape(N, h, c).permute(1, 2, 0), cpu[3][b:b + 1], cpu[4], S, S, 1, c ** -0.5)
             outs.append(o.reshape(C, S * S).t())
         want = torch.stack(outs, 0)
-        want.backward(cot)
+        want.backward(cot.double())
         gpu = [t.clone().to(DEV).requires_grad_(True) for t in (query, k, v, pos, table)]
         got = ops.attention_core(*gpu, heads=h, groups=1, views=1, precision=prec)
         got.backward(cot.to(DEV))
@@ -209,6 +252,9 @@ def test_cfg1_bev50_full_rows(prec):
         print(f"\n[cfg1 {name} prec={prec}] out {e:.3e}")
         assert e < lim["out"]
         for n, a, b_ in zip(("query", "k", "v", "pos", "table"), gpu, cpu):
+            if n == "pos":
+                check_dpos(a.grad, b_.grad, pos, S, Wt, lim["pos"], f"cfg1 {name} prec={prec}")
+                continue
             e = rel_err(a.grad.cpu(), b_.grad)
             print(f"[cfg1 {name} prec={prec}] grad {n} {e:.3e}")
             assert e < lim[n], f"{name} grad {n}: {e:.3e}"

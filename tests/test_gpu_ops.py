@@ -84,6 +84,40 @@ def test_attention_core_forward_backward(cfg, prec):
         assert e < lim, f"grad {n}: rel err {e:.3e}"
 
 
+@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16])
+def test_mid_step_region_move_and_all_padding_half(prec):
+    """Targeted shape for the conditional barriers of the query-stationary kernels (attn_fwd.hip move_region,
+    attn_bwd_q.hip `if (kh) __syncthreads()`): N = 96 keys = one full 64-key step + one step whose second 32-key half
+    is ALL padding.  In the full step the two halves sit 150 table columns apart, so the whole-step box fits no LDS
+    region but each half does: the second half forces a MID-STEP region move (flush, re-anchor, refill between two
+    barriers).  Forward and every gradient against the oracle."""
+    B, V, C, h, g, S, D, N = 1, 1, 64, 2, 1, 34, 4, 96
+    gen = torch.Generator().manual_seed(77)
+    query = torch.randn(B, C, S, S, generator=gen)
+    k, v = torch.randn(B, N, C, generator=gen), torch.randn(B, N, C, generator=gen)
+    Wt = 2 * S * D - 1
+    # table column b = (1 - px)(Wt-1)/4: clusters at b ~ 20, b ~ 170 (150 columns apart), and b ~ 60 for the tail
+    def cluster(b0, n):
+        px = 1 - (b0 + 3 * torch.rand(n, generator=gen)) * 4 / (Wt - 1)
+        py = 0.1 + 0.05 * torch.rand(n, generator=gen)
+        return torch.stack((py, px), -1)
+    pos = torch.cat((cluster(20.0, 32), cluster(170.0, 32), cluster(60.0, 32)), 0)[None]
+    table = torch.randn(h, 2 * S - 1, Wt, generator=gen) * 0.3
+    ins_cpu = [t.clone().requires_grad_(True) for t in (query, k, v, pos, table)]
+    want = _oracle_core(*ins_cpu, h, g, V)
+    cot = torch.randn(want.shape, generator=gen)
+    want.backward(cot)
+    ins_gpu = [t.clone().to(DEV).requires_grad_(True) for t in (query, k, v, pos, table)]
+    got = ops.attention_core(*ins_gpu, heads=h, groups=g, views=V, precision=prec)
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), **TOL[prec])
+    lim = 5e-4 if prec == _lib.PREC_F32 else 5e-2
+    for n, a, b in zip(["query", "k", "v", "pos", "table"], ins_gpu, ins_cpu):
+        e = rel_err(a.grad.cpu(), b.grad)
+        assert e < lim, f"grad {n}: rel err {e:.3e}"
+
+
 def test_attention_rows_are_a_convex_combination_at_scale():
     """Size-independent property at a BEV side the oracle cannot materialise (S=100, N=25000):
     V = const channel pattern -> output equals that pattern for every query (softmax rows sum to 1)."""

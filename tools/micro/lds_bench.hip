@@ -29,9 +29,16 @@ __global__ __launch_bounds__(1024) void k(int iters, unsigned* out, int stride) 
       else if (MODE == 10) { const int q = (j * 2) & 8190; acc += (unsigned)b[q] + (unsigned)b[q + 1]; asm volatile("" ::: "memory"); }
       else if (MODE == 11) { typedef unsigned long long u64x2 __attribute__((ext_vector_type(2))); u64x2 v; const int q = ((j * 2) & 8190) * 8 + 65536; asm volatile("ds_read2_b64 %0, %1 offset1:1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(q) : "memory"); acc += (unsigned)v.x + (unsigned)v.y; }
       else if (MODE == 6) { unsigned v = it; asm volatile("ds_add_u32 %0, %1" :: "v"(j * 4), "v"(v) : "memory"); }
+      else if (MODE == 12) { float v = 1.0f; asm volatile("ds_add_f32 %0, %1" :: "v"(j * 4), "v"(v) : "memory"); }
+      else if (MODE == 13) { unsigned long long v = it; asm volatile("ds_add_u64 %0, %1" :: "v"(65536 + j * 8), "v"(v) : "memory"); }
+      else if (MODE == 14) { unsigned long long v; const int q = (j * 8 + 4) & 65535; asm volatile("ds_read_b64 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(q) : "memory"); acc += (unsigned)v + (unsigned)(v >> 32); }
+      else if (MODE == 15) { float v = 1.0f; if ((lane & 31) == 31) asm volatile("ds_add_f32 %0, %1" :: "v"(j * 4), "v"(v) : "memory"); }
+      else if (MODE == 16) { unsigned v = 0x3f803f80u; asm volatile("ds_pk_add_bf16 %0, %1" :: "v"(j * 4), "v"(v) : "memory"); }
+      else if (MODE == 17) { unsigned long long v; const int q = (j * 8) & 65535; asm volatile("ds_read_b64 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(q) : "memory"); acc += (unsigned)v + (unsigned)(v >> 32); }
+      else if (MODE == 18) { float v = 1.0f; asm volatile("ds_add_f32 %0, %1\n ds_add_f32 %0, %1 offset:256" :: "v"(j * 4), "v"(v) : "memory"); }
     }
   }
-  if (MODE == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (MODE == 6 || MODE >= 12) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();
   out[blockIdx.x * 1024 + tid] = acc + a[tid] + (unsigned)b[tid];
 }
@@ -63,6 +70,13 @@ int main() {
     run<9>("load b32 broadcast(2 addr)", stride);
     run<10>("load 2 x b64 (compiler)", stride);
     run<11>("ds_read2_b64 asm", stride);
+    run<12>("ds_add_f32 asm noret", stride);
+    run<13>("ds_add_u64 asm noret", stride);
+    run<17>("ds_read_b64 asm aligned", stride);
+    run<14>("ds_read_b64 asm addr%8==4", stride);
+    run<15>("ds_add_f32 2 lanes active", stride);
+    run<16>("ds_pk_add_bf16 asm noret", stride);
+    run<18>("2 x ds_add_f32 (per pair)", stride);
   }
   return 0;
 }

@@ -25,8 +25,8 @@ PREC_F32, PREC_BF16 = 0, 1
 SYMBOLS = [
     "bevr_abi_version", "bevr_strerror", "bevr_attn_table_dims", "bevr_attn_key_ws_bytes", "bevr_attn_key_prep",
     "bevr_attn_fwd", "bevr_attn_bwd_q",
-    "bevr_attn_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_project_bev_grid", "bevr_corr_fwd",
-    "bevr_corr_bwd", "bevr_recall_rank", "bevr_dwconv_fwd", "bevr_dwconv_bwd_w",
+    "bevr_attn_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_project_bev_grid", "bevr_project_bev_grid_masked", "bevr_corr_fwd",
+    "bevr_corr_bwd", "bevr_recall_rank", "bevr_dwconv_fwd", "bevr_dwconv_bwd_w", "bevr_affine_warp_fwd", "bevr_affine_warp_bwd",
 ]
 
 
@@ -84,11 +84,14 @@ def lib() -> C.CDLL:
         L.bevr_sample_fwd.argtypes = [fp, fp, fp] + [ip] * 5 + [vp]
         L.bevr_sample_bwd.argtypes = [fp] * 5 + [ip] * 5 + [vp]
         L.bevr_project_bev_grid.argtypes = [fp] * 4 + [ip] * 4 + [vp]
+        L.bevr_project_bev_grid_masked.argtypes = [fp] * 4 + [ip] * 4 + [vp] + [ip] * 3 + [vp]
         L.bevr_corr_fwd.argtypes = [fp] * 5 + [ip] * 4 + [vp]
         L.bevr_corr_bwd.argtypes = [fp] * 8 + [ip] * 4 + [vp]
         L.bevr_recall_rank.argtypes = [fp, vp, ip, vp]
         L.bevr_dwconv_fwd.argtypes = [fp, fp, fp, fp] + [ip] * 7 + [vp]
         L.bevr_dwconv_bwd_w.argtypes = [fp, fp, fp, fp] + [ip] * 6 + [vp]
+        L.bevr_affine_warp_fwd.argtypes = [fp, fp, fp] + [ip] * 4 + [vp]
+        L.bevr_affine_warp_bwd.argtypes = [fp, fp, fp] + [ip] * 4 + [vp]
         for name in SYMBOLS:
             fn = getattr(L, name)
             if name == "bevr_attn_key_ws_bytes":

@@ -3,9 +3,10 @@
 Counterpart of the reference's model/encoder.py: BEVEncoder (:16-128), BEVEncoderStage (:131-234),
 EncoderLayer (:237-466) with identical class names, constructor arguments, forward signatures and
 parameter names (including the never-called down_proj / ffn_tsa / ffn_sca so state_dicts load).
-Differences: the batch size is read from tensors; the eval-only ego-motion warp is one batched
-affine-grid resampling instead of a per-sample torchvision loop (torchvision is absent here, so that
-step is restated from torchvision's documented algorithm: PARITY UNPINNED).
+Differences: the batch size is read from tensors; the ego-motion warp of the history BEV (eval mode, i.e. every
+history frame after the first) is two batched HIP resamplings (ops.affine_warp, csrc/warp.hip) instead of a
+per-sample torchvision loop (torchvision is absent here, so that step is restated from torchvision's documented
+algorithm, fill-mask attenuation included: PARITY UNPINNED).
 """
 import math
 
@@ -33,25 +34,6 @@ class DropPath(nn.Module):
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
         return x * mask / keep
-
-
-def affine_warp(img, angle_deg, translate_xy):
-    """Batched equivalent of torchvision.transforms.functional.affine(img, angle, translate, scale=1, shear=0,
-    BILINEAR, fill=0) on (B, C, H, W) tensors: rotation about the image centre, then translation in pixels.
-    angle_deg, translate_xy: (B,), (B, 2) tensors."""
-    B, C, H, W = img.shape
-    rot = torch.deg2rad(angle_deg.to(img.dtype))
-    cos, sin = torch.cos(rot), torch.sin(rot)
-    tx, ty = translate_xy[:, 0].to(img.dtype), translate_xy[:, 1].to(img.dtype)
-    # inverse map (output pixel -> input pixel), centre at the origin of the pixel-centred grid
-    m = torch.stack((cos, sin, cos * (-tx) + sin * (-ty), -sin, cos, -sin * (-tx) + cos * (-ty)), 1).reshape(B, 2, 3)
-    xs = torch.linspace(-W * 0.5 + 0.5, W * 0.5 - 0.5, W, device=img.device, dtype=img.dtype)
-    ys = torch.linspace(-H * 0.5 + 0.5, H * 0.5 - 0.5, H, device=img.device, dtype=img.dtype)
-    gy, gx = torch.meshgrid(ys, xs, indexing="ij")
-    base = torch.stack((gx, gy, torch.ones_like(gx)), -1).reshape(1, H * W, 3)
-    scale = torch.tensor([0.5 * W, 0.5 * H], device=img.device, dtype=img.dtype)
-    grid = (base @ (m.transpose(1, 2) / scale)).reshape(B, H, W, 2)
-    return F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
 
 
 class EncoderLayer(nn.Module):
@@ -101,10 +83,12 @@ class EncoderLayer(nn.Module):
     def project_history_bev_feat(self, bev, vehicle_pose, return_mask=False):
         """Warp the history BEV into the current frame: rotate by +prev_yaw and translate by (prev - cur)
         pixel offsets, then rotate by -cur_yaw (reference :413-466, two chained bilinear resamplings)."""
-        prev_rot, curr_rot = vehicle_pose[:, 0, 2], vehicle_pose[:, 1, 2]
-        delta = (vehicle_pose[:, 0] - vehicle_pose[:, 1])[:, :2]
-        out = affine_warp(bev, torch.rad2deg(prev_rot), delta)
-        out = affine_warp(out, torch.rad2deg(-curr_rot), torch.zeros_like(delta))
+        from .. import ops
+        pose = vehicle_pose.to(bev.device, torch.float32)
+        prev_rot, curr_rot = pose[:, 0, 2], pose[:, 1, 2]
+        delta = (pose[:, 0] - pose[:, 1])[:, :2]
+        out = ops.affine_warp(bev, prev_rot, delta)                       # HIP: csrc/warp.hip, one launch per warp
+        out = ops.affine_warp(out, -curr_rot, torch.zeros_like(delta))
         if return_mask:
             return out, out != 0
         return out

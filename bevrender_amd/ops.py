@@ -368,15 +368,24 @@ def sample_features(feat_nchw: torch.Tensor, pos: torch.Tensor, groups: int) -> 
 
 
 def project_bev_grid(points_3d: torch.Tensor, cam_inv: torch.Tensor, Kmat: torch.Tensor, img_w: int,
-                     img_h: int) -> torch.Tensor:
-    """points_3d (4, P), cam_inv (ncam, 4, 4), Kmat (ncam, 3, 3) -> (ncam, 2, P) normalised (x, y)."""
-    _require_gpu(points_3d, cam_inv, Kmat)
+                     img_h: int, gray_ref: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """points_3d (4, P), cam_inv (ncam, 4, 4), Kmat (ncam, 3, 3) -> (ncam, 2, P) normalised (x, y).
+    gray_ref (ncam, C, H, W) uint8, optional: the reference images of the grey-pixel mask (remove_ref_in_gray)."""
+    _require_gpu(points_3d, cam_inv, Kmat, gray_ref)
     pts = points_3d.float().contiguous()
     ci, km = cam_inv.float().contiguous(), Kmat.float().contiguous()
     ncam, P = ci.shape[0], pts.shape[1]
     out = torch.empty(ncam, 2, P, device=pts.device, dtype=torch.float32)
-    _lib.check(_lib.lib().bevr_project_bev_grid(_ptr(pts), _ptr(ci), _ptr(km), _ptr(out), ncam, P, img_w, img_h,
-                                                _stream()), "bevr_project_bev_grid")
+    if gray_ref is None:
+        _lib.check(_lib.lib().bevr_project_bev_grid(_ptr(pts), _ptr(ci), _ptr(km), _ptr(out), ncam, P, img_w, img_h,
+                                                    _stream()), "bevr_project_bev_grid")
+        return out
+    if gray_ref.dtype != torch.uint8 or gray_ref.dim() != 4 or gray_ref.shape[0] != ncam:
+        raise ValueError("gray_ref must be a (ncam, C, H, W) uint8 tensor")
+    ref = gray_ref.contiguous()
+    _lib.check(_lib.lib().bevr_project_bev_grid_masked(_ptr(pts), _ptr(ci), _ptr(km), _ptr(out), ncam, P, img_w, img_h,
+                                                       _ptr(ref), ref.shape[1], ref.shape[2], ref.shape[3], _stream()),
+               "bevr_project_bev_grid_masked")
     return out
 
 
@@ -423,6 +432,48 @@ def recall_rank(D: torch.Tensor) -> torch.Tensor:
     rank = torch.empty(n, device=D.device, dtype=torch.int32)
     _lib.check(_lib.lib().bevr_recall_rank(_ptr(D), _ptr(rank), n, _stream()), "bevr_recall_rank")
     return rank
+
+
+# --------------------------------------------------------------------------------------------------
+# ego-motion warp of the history BEV (csrc/warp.hip)
+# --------------------------------------------------------------------------------------------------
+class _AffineWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, theta):
+        _require_gpu(img, theta)
+        img, theta = img.float().contiguous(), theta.float().contiguous()
+        B, Cc, H, W = img.shape
+        out = torch.empty_like(img)
+        _lib.check(_lib.lib().bevr_affine_warp_fwd(_ptr(img), _ptr(theta), _ptr(out), B, Cc, H, W, _stream()),
+                   "bevr_affine_warp_fwd")
+        ctx.save_for_backward(theta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (theta,) = ctx.saved_tensors
+        dout = dout.float().contiguous()
+        B, Cc, H, W = dout.shape
+        dimg = torch.zeros_like(dout)
+        _lib.check(_lib.lib().bevr_affine_warp_bwd(_ptr(dout), _ptr(theta), _ptr(dimg), B, Cc, H, W, _stream()),
+                   "bevr_affine_warp_bwd")
+        return dimg, None
+
+
+def affine_theta(angle_rad: torch.Tensor, translate_xy: torch.Tensor) -> torch.Tensor:
+    """(B, 6) inverse affine matrices of torchvision.transforms.functional.affine(angle, translate, scale=1, shear=0)
+    about the image centre, in pixel units: [cos, sin, -cos tx - sin ty; -sin, cos, sin tx - cos ty].  Built on the
+    device from pose tensors (the reference's per-sample math.degrees / .item() round trips, model/encoder.py:431-453)."""
+    c, s = torch.cos(angle_rad), torch.sin(angle_rad)
+    tx, ty = translate_xy[:, 0], translate_xy[:, 1]
+    return torch.stack((c, s, -c * tx - s * ty, -s, c, s * tx - c * ty), 1).float()
+
+
+def affine_warp(img: torch.Tensor, angle_rad: torch.Tensor, translate_xy: torch.Tensor) -> torch.Tensor:
+    """Batched torchvision F.affine(img[b], degrees(angle[b]), translate[b], 1.0, 0, BILINEAR, fill=0) on (B, C, H, W):
+    rotation about the image centre then translation in pixels; bilinear, zero padding, and the second attenuation
+    by the resampled ones channel that torchvision applies when a fill value is given."""
+    return _AffineWarp.apply(img, affine_theta(angle_rad.to(img.device), translate_xy.to(img.device)))
 
 
 # --------------------------------------------------------------------------------------------------

@@ -15,11 +15,12 @@
  *   - tensors are dense row-major with the layouts written next to each argument.
  *
  * Reference functions replaced (paths relative to the reference repo):
- *   bevr_project_bev_grid   model/bev_cmr_proj.py:61-113  (bev_grid_to_camera + get_in_bound_mask)
+ *   bevr_project_bev_grid[_masked]  model/bev_cmr_proj.py:61-124  (bev_grid_to_camera + get_in_bound_mask)
  *   bevr_sample_fwd/bwd     F.grid_sample at model/SCA_deform_attn.py:290-301, model/TSA_deform_attn.py:210-217
  *   bevr_attn_fwd/bwd_*     model/SCA_deform_attn.py:331-413, model/TSA_deform_attn.py:245-333
  *                           (QK^T*scale + bilinear RPE bias + softmax + PV, never materialised)
  *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
+ *   bevr_affine_warp_fwd/bwd  model/encoder.py:413-466 (project_history_bev_feat: torchvision F.affine, twice)
  *   bevr_corr_fwd/bwd       train.py:554 (2 - 2 cam map^T) and the pairwise distance inside
  *                           loss/contrastive_loss.py:10-19 / loss/lift_loss.py:13-22
  */
@@ -157,6 +158,13 @@ int bevr_sample_bwd(const float* feat, const float* pos, const float* dout, floa
  * ---------------------------------------------------------------------------------------------- */
 int bevr_project_bev_grid(const float* points_3d, const float* cam_inv, const float* Kmat, float* out,
                           int ncam, int P, int img_w, int img_h, void* stream);
+/* The same with the optional grey-pixel mask of model/bev_cmr_proj.py:114-122 (remove_ref_in_gray):
+ *   ref_img [ncam][ref_c][ref_h][ref_w] uint8 (device), one reference image per camera, ref_h >= img_h - 1,
+ *   ref_w >= img_w - 1; a point whose truncated pixel has exactly three channels equal to 128 is pinned like an
+ *   out-of-bound point.  ref_img == NULL: identical to bevr_project_bev_grid. */
+int bevr_project_bev_grid_masked(const float* points_3d, const float* cam_inv, const float* Kmat, float* out,
+                                 int ncam, int P, int img_w, int img_h, const uint8_t* ref_img, int ref_c,
+                                 int ref_h, int ref_w, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ground <-> aerial correlation: D[i][j] = 2 - 2 * <cam_i, map_j>  (train.py:554) on raw or
@@ -185,6 +193,17 @@ int bevr_dwconv_fwd(const float* x, const float* w, const float* bias, float* y,
                     int B, int H, int W, int C, int k, int nhwc, int flip, void* stream);
 int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
                       int B, int H, int W, int C, int k, int nhwc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ego-motion warp of the history BEV (model/encoder.py:413-466): one torchvision-style affine resampling,
+ * bilinear, zero padding, fill = 0 -- out = bilinear(img) * bilinear(ones) -- for a whole batch.
+ *   img, out [B][C][H][W] float      theta [B][6] float (device): torchvision's INVERSE affine matrix in pixel units
+ *   about the image centre, rows (m0 m1 m2; m3 m4 m5): the source pixel of output pixel (x, y) is
+ *   (m0 X + m1 Y + m2 + (W-1)/2, m3 X + m4 Y + m5 + (H-1)/2), X = x - W/2 + 1/2, Y = y - H/2 + 1/2.
+ * backward: dimg ACCUMULATED from dout with the same theta (caller zeroes dimg).
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_affine_warp_fwd(const float* img, const float* theta, float* out, int B, int C, int H, int W, void* stream);
+int bevr_affine_warp_bwd(const float* dout, const float* theta, float* dimg, int B, int C, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -264,9 +264,11 @@ def sample_3d_points(bound: Dict[str, float], S: int, D: int, z_shift: float) ->
 
 
 def bev_grid_to_camera(points_3d: Tensor, imu_to_rgb: Sequence[np.ndarray], K: Sequence[np.ndarray],
-                       img_width: int, img_height: int, ori_img_width: int, ori_img_height: int) -> List[Tensor]:
+                       img_width: int, img_height: int, ori_img_width: int, ori_img_height: int,
+                       gray_ref: Optional[Sequence[Tensor]] = None) -> List[Tensor]:
     """Per camera (2, h, w, z) normalised (x, y).  K is NOT mutated here (the reference scales the caller's
-    arrays in place, bev_cmr_proj.py:41-46; the scaled copy is what is used below)."""
+    arrays in place, bev_cmr_proj.py:41-46; the scaled copy is what is used below).
+    gray_ref: per camera a (C, H, W) uint8 reference image -> the remove_ref_in_gray mask of :114-122."""
     sx, sy = img_width / ori_img_width, img_height / ori_img_height
     _, h, w, z = points_3d.shape
     pts = points_3d.reshape(4, -1)
@@ -284,6 +286,11 @@ def bev_grid_to_camera(points_3d: Tensor, imu_to_rgb: Sequence[np.ndarray], K: S
         uv = uv.div(uv[-1])[:2]                                                # :74
         iu = uv.to(torch.int32)                                                # :106 truncation toward zero
         mask = iu[1].ge(0) & iu[1].lt(img_height - 1) & iu[0].ge(0) & iu[0].lt(img_width - 1)
+        if gray_ref is not None:                                               # :114-122
+            ref_img = gray_ref[len(out)]
+            ip = iu.masked_fill(~mask, 0).long()
+            values = ref_img[:, ip[1], ip[0]]
+            mask = mask & ((values == 128).sum(0) != 3)
         uv = uv.masked_fill(~mask, 0)                                          # :76
         u = uv[0] / (img_width - 1)
         v_ = uv[1] / (img_height - 1)
@@ -444,3 +451,48 @@ def triplet_margin_loss(cam: Tensor, mp: Tensor, miner_margin: float = 0.2, loss
 def pairwise_corr(cam: Tensor, mp: Tensor) -> Tensor:
     """The explicit ground<->aerial correlation of train.py:554: 2 - 2 cam @ map^T."""
     return 2.0 - 2.0 * cam @ mp.t()
+
+
+# --------------------------------------------------------------------------- #
+# 6. ego-motion warp of the history BEV  (model/encoder.py:413-466) -- PARITY UNPINNED
+# --------------------------------------------------------------------------- #
+def tv_affine(img: Tensor, angle_deg: float, translate, fill: float = 0.0) -> Tensor:
+    """torchvision.transforms.functional.affine(img (C,H,W), angle, translate, scale=1.0, shear=0,
+    interpolation=BILINEAR, fill=fill) restated from torchvision's published tensor path (the package is absent from
+    this image, version un-pinned by the reference: PARITY UNPINNED):
+      _get_inverse_affine_matrix(center=(0,0), angle, translate, 1, (0,0)): with rot = radians(angle),
+          M = [cos, sin, -cos tx - sin ty;  -sin, cos, sin tx - cos ty]
+      _gen_affine_grid: pixel-centre grid X in linspace(-W/2 + 1/2, W/2 - 1/2, W) (Y alike), grid = [X Y 1] M^T / (W/2, H/2)
+      _apply_grid_transform: with a fill value a ones channel is appended, grid_sample(bilinear, zeros,
+          align_corners=False) resamples both, and (bilinear) out = img * mask + (1 - mask) * fill."""
+    C, H, W = img.shape
+    rot = math.radians(float(angle_deg))
+    tx, ty = float(translate[0]), float(translate[1])
+    c, s = math.cos(rot), math.sin(rot)
+    m = [c, s, c * (-tx) + s * (-ty), -s, c, -s * (-tx) + c * (-ty)]
+    theta = torch.tensor(m, dtype=img.dtype).reshape(1, 2, 3)
+    base = torch.empty(1, H, W, 3, dtype=img.dtype)
+    base[..., 0].copy_(torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W, dtype=img.dtype))
+    base[..., 1].copy_(torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H, dtype=img.dtype).unsqueeze(-1))
+    base[..., 2].fill_(1)
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H], dtype=img.dtype)
+    grid = base.view(1, H * W, 3).bmm(rescaled).view(1, H, W, 2)
+    x = torch.cat((img[None], torch.ones(1, 1, H, W, dtype=img.dtype)), 1)
+    y = F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    mask = y[:, -1:]
+    out = y[:, :-1] * mask + (1.0 - mask) * fill
+    return out[0]
+
+
+def project_history_bev_feat(bev: Tensor, vehicle_pose: Tensor) -> Tensor:
+    """EncoderLayer.project_history_bev_feat, model/encoder.py:413-466: per sample, rotate by +prev_yaw and translate
+    by (prev - cur) pixel offsets, then rotate by -cur_yaw: two chained bilinear resamplings with fill 0.
+    vehicle_pose (B, 2, 3) = [pixel_x, pixel_y, yaw_rad] of the previous and the current frame."""
+    outs = []
+    for i in range(bev.shape[0]):
+        prev_rot, curr_rot = vehicle_pose[i, :, 2]
+        delta_x, delta_y, _ = vehicle_pose[i, 0] - vehicle_pose[i, 1]
+        p = tv_affine(bev[i], math.degrees(prev_rot), (delta_x, delta_y))
+        p = tv_affine(p, math.degrees(-curr_rot), (0.0, 0.0))
+        outs.append(p)
+    return torch.stack(outs, 0)

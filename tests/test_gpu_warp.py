@@ -30,7 +30,9 @@ def test_project_history_matches_oracle(shape):
     pose[0] = 0                                                       # one sample: no motion
     want = O.project_history_bev_feat(bev, pose)
     got = EncoderLayer.project_history_bev_feat(None, bev.to(DEV), pose.to(DEV))
-    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    # two chained float32 resamplings on each side: a source coordinate within rounding of a pixel boundary picks the
+    # neighbouring cell (the interpolated value is continuous there): 1e-4 absolute on N(0,1) data
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_array_equal(got[0].cpu().numpy(), bev[0].numpy())        # zero pose is the identity, exactly
 
 
@@ -70,7 +72,7 @@ def test_warp_backward_matches_autograd_of_the_oracle():
     from bevrender_amd.model.encoder import EncoderLayer
     bg = bev.clone().to(DEV).requires_grad_(True)
     EncoderLayer.project_history_bev_feat(None, bg, pose.to(DEV)).backward(cot.to(DEV))
-    np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), bc.grad.numpy(), rtol=1e-4, atol=1e-4)
 
 
 def test_encoder_layer_eval_mode_warps_the_history():

@@ -52,7 +52,7 @@ constexpr int NCOL = 8;   // query columns per workgroup (one per wave)
 
 template <int PREC> struct LdsQ {
   static constexpr int EB = Elem<PREC>::bytes;
-  static constexpr int CAP = PREC == BEVR_PREC_BF16 ? 52 : 48;   // region capacity (table columns)
+  static constexpr int CAP = region_cap_bwd_q(PREC);   // region capacity (table columns)
   static constexpr int R_STRIDE = 32 * EB + 16;   // row-layout tiles (K, V): bytes per key row
   static constexpr int T_STRIDE = KT * EB + 16;   // transposed tile (Kt): bytes per channel row
   static constexpr int R_BYTES = KT * R_STRIDE;
@@ -60,16 +60,17 @@ template <int PREC> struct LdsQ {
   static constexpr int C_BYTES = KT * 16 + 32;
   static constexpr int BUF = 2 * R_BYTES + T_BYTES + C_BYTES;
   static constexpr int ENT = PREC == BEVR_PREC_BF16 ? 4 : 8;   // table-window entry: (T[y], T[y+1]) as bf16x2 / f32x2
-  static constexpr int WCOLS = CAP + 2;           // + two "kill" columns of -1e30: where padded keys point their taps
+  static constexpr int WCOLS = CAP + 2;           // + two "kill" columns of -1e30: where masked keys point their taps
   static constexpr int WIN = WCOLS * WIN_PITCH * ENT;
   static constexpr int CELLS = CAP * WIN_PITCH;   // accumulation window: one 64-bit cell per table entry (+ kill columns)
   static constexpr int PCK = NWAVE * 32 * (PREC == BEVR_PREC_BF16 ? 16 : 32);   // per wave: one 32-key half at a time
   // bf16 mode: the tile's dO fragments live in LDS (fragment order, re-read every step) instead of 8 registers
-  static constexpr int QDO = PREC == BEVR_PREC_BF16 ? NCOL * 2 * 64 * 16 : 16;     // per-wave (column, key) constants
+  static constexpr int QDO = PREC == BEVR_PREC_BF16 ? NCOL * 2 * 64 * 16 : 16;
   static constexpr int ACCB = 8;   // bytes per accumulation cell (see AccCell)
   static constexpr int TOTAL = BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK + QDO;
 };
 
+constexpr int QROWS = 31;   // query rows per tile: lane 31 of each 32-lane half carries no query (see the kernel header)
 
 // round-to-nearest float -> int in one instruction (floor(x + 0.5))
 __device__ __forceinline__ int cvt_rpi(float x) {
@@ -78,20 +79,23 @@ __device__ __forceinline__ int cvt_rpi(float x) {
   return r;
 }
 
+// the value of the lane below (lane - 1) across the whole wave; lane 0 receives 0 (v_mov_b32_dpp wave_shr:1)
+__device__ __forceinline__ float lane_below(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, true));
+}
+
 // Fixed-point accumulation cell: 64-bit in both precision modes.
 //   unit = bound * 2^-30, bound >= max |dS| over all pairs (handed in by the caller as grad_scale);
-//   one contribution |dS * w| <= bound converts to a 32-bit integer (v_cvt_rpi, round to nearest: truncation would
-//   bias the sum of many small same-sign contributions) and is sign-extended into the 64-bit cell, so a cell can
-//   take 2^33 contributions of the largest possible size before it wraps -- more than a launch has pairs per
-//   cell.  32-bit cells (tried in round 1 for the bf16 mode: ds_add_u32 is 4.4 clk, ds_add_u64 6.3) cannot hold
-//   both ends: a cell of the pinned-key box receives ~10^5 contributions per region, so a unit that is safe against
-//   wrap-around is ~bound * 2^-14, far above a typical contribution (P ~ 1/N): at S = 200 the table gradient came
-//   out 67 % wrong against the f32 mode (tests/test_gpu_fullsize.py).  Native LDS float atomics are no way out on
-//   gfx950 either: ds_add_f32 / ds_pk_add_bf16 retire ~3 clk per active LANE (193 clk per wave instruction;
-//   tools/micro/lds_bench.hip).
-template <int PREC> struct AccCell {
+//   one contribution converts to a 32-bit integer (v_cvt_rpi, round to nearest: truncation would bias the sum of
+//   many small same-sign contributions) and is sign-extended into the 64-bit cell, so a cell can take 2^32
+//   contributions of the largest possible size before it wraps -- more than a launch has pairs per cell.
+//   32-bit cells (round 1, bf16 mode: ds_add_u32 is 4.4 clk, ds_add_u64 6.3) cannot hold both ends: a cell of the
+//   pinned-key box receives ~10^5 contributions per region, so a unit that is safe against wrap-around is
+//   ~bound * 2^-14, far above a typical contribution (P ~ 1/N): at S = 200 the table gradient came out 67 % wrong
+//   against the f32 mode (tests/test_gpu_fullsize.py).  Native LDS float atomics are no way out on gfx950 either:
+//   ds_add_f32 / ds_pk_add_bf16 retire ~3 clk per active LANE (193 clk per wave instruction; tools/micro/lds_bench.hip).
+struct AccCell {
   typedef unsigned long long type;
-  static constexpr float rescale = 1.0f;
   static __device__ __forceinline__ type from(float x) {
     const int v = cvt_rpi(x);
     return ((unsigned long long)(unsigned)(v >> 31) << 32) | (unsigned)v;
@@ -114,17 +118,18 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   constexpr int CAP = L::CAP;
   constexpr int ENT = L::ENT;
   static_assert(L::TOTAL <= (PREC == BEVR_PREC_BF16 ? 80 : 160) * 1024, "LDS budget");
+  static_assert(NCOL == QCOLS, "group_width() assumes this tile width");
   // separate LDS objects: loads of the staged tiles / table window may be scheduled across the window atomics
   __shared__ __attribute__((aligned(16))) char smem[L::BUF];
   __shared__ __attribute__((aligned(16))) char win[L::WIN];
-  typedef AccCell<PREC> Acc;
+  typedef AccCell Acc;
   typedef typename Acc::type acc_t;
   __shared__ __attribute__((aligned(16))) acc_t accw[L::WCOLS * WIN_PITCH];
   typedef ColKeyT<PREC> CK;
   __shared__ __attribute__((aligned(16))) CK pck_all[NWAVE * 32];
   __shared__ __attribute__((aligned(16))) char qdo[L::QDO];
 
-  const int n_rb = d.Sp / 32;
+  const int n_rb = (d.S + QROWS - 1) / QROWS;
   const int n_cb = (d.S + NCOL - 1) / NCOL;
   const int n_tile = n_rb * n_cb;
   const int n_ph = d.n_prob * d.heads;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   const int col = wave;
   CK* pck = pck_all + wave * 32;
   const int Mp = d.S * d.Sp;
-  const int i0 = rb * 32;
+  const int i0 = rb * QROWS;
 
   const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB;
   const char* dOh = dO + ((size_t)ph * Mp) * 32 * EB;
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   const int pg = prob * d.groups + grp;
   const KeyW* kws = reinterpret_cast<const KeyW*>(key_ws) + (size_t)pg * d.Np;
   const StepBox* kbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / 32);
+  const StepBox* gbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_gbox_offset(d)) + (size_t)pg * (d.Np / 32) * N_GROUP;
   const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
   float* dtb = dtable + (size_t)hd * d.Wp * (d.Hp + 1);
   const int Hp8 = d.Hp * 8;
@@ -160,14 +166,19 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   const int j_last = min(j_first + NCOL - 1, d.S - 1);
   const float jrx_lo = (float)j_first * rx, jrx_hi = (float)j_last * rx;
   // dS = ln2 * P * (dP - delta): the ln2 is folded into the fixed-point scale here and into dQ at the end
-  const float gscale = grad_scale[0] * Acc::rescale * BEVR_LN2, ginv = grad_scale[1] / Acc::rescale;
+  const float gscale = grad_scale[0] * BEVR_LN2, ginv = grad_scale[1];
 
-  // this wave's query column
+  // this wave's query column; this lane's query row.  Lanes 0..30 of each half carry the tile's 31 queries, lane 31
+  // none: its slot is the 32nd table row the tile's taps reach (query 30's lower tap), which lets every lane add the
+  // PRE-SUMMED contribution of its own upper tap and the lower tap of the lane below -- one atomic per table column
+  // and key instead of two.  A lane without a query (lane 31, rows past the grid, columns past the grid) computes on
+  // a clamped copy of a real query with dO = delta = 0: its dS is exactly 0.
   const int jcol = j_first + col;
-  const bool live = jcol < d.S;
-  const int jc = live ? jcol : d.S - 1;   // columns past the grid: a clamped copy that contributes nothing
+  const int qrow = i0 + lq;
+  const bool live = jcol < d.S && lq < QROWS && qrow < d.S;
+  const int jc = min(jcol, d.S - 1);
   const float jrx = (float)jc * rx;
-  const size_t mq = (size_t)jc * d.Sp + i0 + lq;
+  const size_t mq = (size_t)jc * d.Sp + min(qrow, d.S - 1);
   Frag<PREC> qf, dof;
   qf.load(Qh + mq * 32 * EB, hi);
   dof.load(dOh + mq * 32 * EB, hi);
@@ -249,33 +260,45 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   };
 
   stage_load(0);
-  if (tid < 2 * WIN_PITCH) {   // the two kill columns of the table window; their accumulation cells only ever get +0
+  // the two kill columns of the table window; their accumulation cells only ever get +0.  The accumulation window
+  // starts clean.
+  for (int c = tid; c < L::WCOLS * WIN_PITCH; c += TQ) accw[c] = 0;
+  if (tid < 2 * WIN_PITCH) {
     if constexpr (PREC == BEVR_PREC_BF16)
       *reinterpret_cast<unsigned*>(win + (CAP * WIN_PITCH + tid) * ENT) = pack_bf16x2(BEVR_NEG_BIG, BEVR_NEG_BIG);
     else
       *reinterpret_cast<f32x2*>(win + (CAP * WIN_PITCH + tid) * ENT) = f32x2{BEVR_NEG_BIG, BEVR_NEG_BIG};
-    accw[CAP * WIN_PITCH + tid] = 0;
   }
   __syncthreads();
 
   Region rg;
   rg.ax0 = -(1 << 28);
   rg.ay0 = 0;
-  bool acc_live = false;   // the accumulation window holds un-flushed gradient
+  // box of the region (region coordinates) that has received gradient since the last flush; uniform.  c1 < c0: clean.
+  int dc0 = 1 << 20, dc1 = -1, dr0 = 1 << 20, dr1 = -1;
 
-  // drain the shared window of region `r` (all threads): fixed point -> float, non-zero cells only, then clear.
-  // A column of the window is 64 consecutive rows of one table column: 256-byte contiguous atomics.
-  auto flush_and_clear = [&](const Region& r, bool do_flush) {
-    for (int cell = tid; cell < L::CELLS; cell += TQ) {
-      const acc_t v = accw[cell];
-      accw[cell] = 0;
-      if (do_flush && v != 0) {
-        const int c = cell / WIN_PITCH, row = cell % WIN_PITCH;
-        BEVR_ASSERT(r.ax0 + c + d.x_off < d.Wp);   // only columns of the real padded table ever receive gradient
-        const float f = Acc::to_float(v) * ginv;
-        atomicAdd(dtb + (size_t)(r.ax0 + c + d.x_off) * Hq + (size_t)(i0 + r.ay0 + d.y_off + row), f);
+  // drain the dirty box of the shared window of region `r` (all threads): fixed point -> float, non-zero cells only,
+  // then clear.  A column of the window is 64 consecutive rows of one table column: contiguous float atomics.
+  auto flush_and_clear = [&](const Region& r) {
+    if (dc1 >= dc0) {
+      const int nr = dr1 - dr0 + 1, ncell = nr * (dc1 - dc0 + 1);
+      const float inv_nr = 1.0f / (float)nr;
+      for (int u = tid; u < ncell; u += TQ) {
+        int c = (int)((float)u * inv_nr);          // u / nr, corrected for the float estimate
+        int row = u - c * nr;
+        if (row < 0) { row += nr; --c; }
+        if (row >= nr) { row -= nr; ++c; }
+        const int cell = (dc0 + c) * WIN_PITCH + dr0 + row;
+        const acc_t v = accw[cell];
+        if (v != 0) {
+          accw[cell] = 0;
+          BEVR_ASSERT(r.ax0 + dc0 + c + d.x_off < d.Wp);   // only columns of the real padded table ever receive gradient
+          const float f = Acc::to_float(v) * ginv;
+          atomicAdd(dtb + (size_t)(r.ax0 + dc0 + c + d.x_off) * Hq + (size_t)(i0 + r.ay0 + d.y_off + dr0 + row), f);
+        }
       }
     }
+    dc0 = 1 << 20; dc1 = -1; dr0 = 1 << 20; dr1 = -1;
   };
 
 #ifdef BEVR_PROF
@@ -306,114 +329,185 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
 #pragma unroll 1
     for (int kh = 0; kh < 2; ++kh) {   // the two 32-key halves of the step, one after the other
       const KeyW* kc = kc0 + kh * 32;
-      // ---- this half's table window ------------------------------------------------------------------
       const StepBox sbh = kh ? sb1 : sb0;
-      const WinInfo wi = wi_step.ok ? wi_step : make_wininfo(sbh, jrx_lo, jrx_hi, CAP);
-      const bool use_win = wi.ok != 0;   // workgroup-uniform
-      BEVR_ASSERT_WG_UNIFORM((int)use_win * 65536 + wi.xlo * 131 + wi.amin * 7 + wi.ncols);
-      if (use_win && !region_contains(rg, wi, CAP)) {
-        if (kh) __syncthreads();   // mid-step move: every wave must be done with the first half's taps and adds
-        flush_and_clear(rg, acc_live);
-        rg = region_anchor(wi, d, i0, CAP);
-        {   // fill the region: one wave-wide load per table column (lane = row)
-          const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
-          BEVR_ASSERT(i0 + rg.ay0 + d.y_off >= 0 && i0 + rg.ay0 + d.y_off + WIN_PITCH <= d.Hp && rg.ax0 + d.x_off >= 0);
-          for (int c = wave; c < CAP; c += NWAVE) {
-            const f32x2 v = region_entry(tbl, d, rg, c, y0);
-            if constexpr (PREC == BEVR_PREC_BF16)
-              *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
-            else
-              *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = v;
-          }
-        }
-        acc_live = true;
-        __syncthreads();
-        PROF_ADD(5, 1);
-      }
-      if (use_win) {
-        // this wave's (column, key) constants for the 32 keys of this half: lane & 31 = key (both lane halves write
-        // the same values); read back by this wave only -- a wave's LDS operations execute in order
-        const KeyW kw = kc[lq];
-        const float tx = jrx + (kw.b - (float)rg.ax0);
-        const float xf = floorf(tx);
-        CK e;
-        const bool dead = step * KT + kh * 32 + lq >= d.N;   // padded key: taps in the kill column => P = 0
-        const float fx = tx - xf, fy = kw.fy;
-        if (dead) e.set(1.f, 0.f, 0.f, 0.f);
-        else e.set((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy, fx * (1.0f - fy), fx * fy);
-        e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (sbh.amin - rg.ay0);   // arow8 is relative to the half's first row
-        pck[lq] = e;
-      }
-      Frag<PREC> kf, vkf, ktf;
-      kf.load(base + (kh * 32 + lq) * L::R_STRIDE, hi);
-      vkf.load(base + L::R_BYTES + (kh * 32 + lq) * L::R_STRIDE, hi);
-      load_perm(ktf, base + 2 * L::R_BYTES + lq * L::T_STRIDE + kh * 32 * EB, hi);
       const bool last = (step == n_step - 1) && d.N < d.Np;
+      // How this half is served (all workgroup-uniform: functions of the scalar-loaded boxes only):
+      //   its own box (or the whole step's) fits a region  -> one windowed pass over all 32 keys      (n_pass = 1)
+      //   else, the half has groups (attn_tile.h)          -> one windowed pass per non-empty group
+      //   else                                             -> the global-memory path                  (n_pass = 0)
+      const WinInfo wi_half = wi_step.ok ? wi_step : make_wininfo(sbh, jrx_lo, jrx_hi, CAP);
+      const StepBox* gb = gbox + (size_t)(2 * step + kh) * N_GROUP;
+      const bool grouped = !wi_half.ok && sbh.amax >= sbh.amin && gb[0].amin != GROUPS_NONE;
+      const int n_pass = wi_half.ok ? 1 : (grouped ? N_GROUP : 0);
+      bool moved_in_half = false;
 
-      f32x16 s, dp;
-      {
-        // launder the row constants: otherwise the splatted 16-register accumulator seeds are hoisted out of the
-        // step loop and live in scratch (reloaded every step, a full-latency miss each time)
-        float nl = -lse, nd = -dlt;
-        asm volatile("" : "+v"(nl), "+v"(nd));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
-      }
-      if constexpr (PREC == BEVR_PREC_BF16) {
-        const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 2 * 64 + lane;
-        Frag<PREC> dos;
-        dos.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
-        dos.v[1] = __builtin_bit_cast(bf16x8, qd[64]);
-        s = mma_frag(kf, qf, s);        // S^T - LSE
-        dp = mma_frag(vkf, dos, dp);    // dP^T - delta
-      } else {
-        s = mma_frag(kf, qf, s);
-        dp = mma_frag(vkf, dof, dp);
-      }
-      PROF_TD(t2, s[0] + dp[15]);
-      PROF_ADD(1, t2 - t1);
-
-      if (use_win) {
-        // The LDS atomics are ordered memory operations for the compiler: it moves no load across them.  So
-        // the loop is software-pipelined by hand -- the taps of key r + 1 and the constants of key r + 2 are
-        // requested before the atomics of key r are issued, and their latency hides behind key r's arithmetic.
-        typedef typename std::conditional<PREC == BEVR_PREC_BF16, unsigned, f32x2>::type tap_t;
-        auto read_tap = [&](int cell, tap_t& a, tap_t& b) {
-          const char* p = win + (cell + lq) * ENT;
-          a = *reinterpret_cast<const tap_t*>(p);
-          b = *reinterpret_cast<const tap_t*>(p + WIN_PITCH * ENT);
-        };
-        const CK* pk = pck;
-        CK e0 = pk[crow(0, hi)], e1 = pk[crow(1, hi)];
-        tap_t ta, tb;
-        read_tap(e0.cell, ta, tb);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          tap_t na = ta, nb = tb;
-          CK e2 = e1;
-          if (r + 1 < 16) read_tap(e1.cell, na, nb);
-          if (r + 2 < 16) e2 = pk[crow(r + 2, hi)];
-          float sv;
-          if constexpr (PREC == BEVR_PREC_BF16) {
-            sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ta), __builtin_bit_cast(bf16x2, e0.wA), s[r],
-                                                 false);
-            sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, tb), __builtin_bit_cast(bf16x2, e0.wB), sv,
-                                                 false);
-          } else {
-            sv = fmaf(tb[1], e0.w11(), fmaf(tb[0], e0.w10(), fmaf(ta[1], e0.w01(), fmaf(ta[0], e0.w00(), s[r]))));
-          }
-          const float ds = fast_exp2(sv) * dp[r];   // padded keys: -1e30 from the kill column => 0
-          s[r] = ds;
-          // table gradient: four fixed-point adds into the shared window (order-free, so no per-wave windows)
-          const float dss = ds * gscale;
-          acc_t* g = accw + (e0.cell + lq);
-          atomicAdd(g, Acc::from(dss * e0.w00()));
-          atomicAdd(g + 1, Acc::from(dss * e0.w01()));
-          atomicAdd(g + WIN_PITCH, Acc::from(dss * e0.w10()));
-          atomicAdd(g + WIN_PITCH + 1, Acc::from(dss * e0.w11()));
-          e0 = e1; e1 = e2; ta = na; tb = nb;
+#pragma unroll 1
+      for (int pass = 0; pass < n_pass; ++pass) {
+        WinInfo wi = wi_half;
+        int gsel = -1;
+        if (grouped) {
+          const StepBox gbx = gb[pass];
+          if (gbx.amax < gbx.amin) continue;        // empty group (uniform)
+          wi = make_wininfo(gbx, jrx_lo, jrx_hi, CAP);
+          gsel = pass;
+          BEVR_ASSERT(wi.ok);
         }
-      } else {
+        BEVR_ASSERT_WG_UNIFORM(wi.xlo * 131 + wi.amin * 7 + wi.ncols + gsel * 977);
+        // ---- this pass's table window ------------------------------------------------------------------
+        if (!region_contains(rg, wi, CAP)) {
+          // every wave must be done with the taps and adds of the previous half / pass of this step
+          if (kh || pass || moved_in_half) __syncthreads();
+          flush_and_clear(rg);
+          rg = region_anchor(wi, d, i0, CAP);
+          {   // fill the region: one wave-wide load per table column (lane = row)
+            const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
+            BEVR_ASSERT(i0 + rg.ay0 + d.y_off >= 0 && i0 + rg.ay0 + d.y_off + WIN_PITCH <= d.Hp && rg.ax0 + d.x_off >= 0);
+            for (int c = wave; c < CAP; c += NWAVE) {
+              const f32x2 v = region_entry(tbl, d, rg, c, y0);
+              if constexpr (PREC == BEVR_PREC_BF16)
+                *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
+              else
+                *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = v;
+            }
+          }
+          moved_in_half = true;
+          __syncthreads();
+          PROF_ADD(5, 1);
+        }
+        {   // the pass's cells become dirty (region coordinates)
+          dc0 = min(dc0, wi.xlo - rg.ax0);
+          dc1 = max(dc1, wi.xlo - rg.ax0 + wi.ncols - 1);
+          dr0 = min(dr0, wi.amin - rg.ay0);
+          dr1 = max(dr1, wi.amin - rg.ay0 + wi.nrows);
+        }
+        {
+          // this wave's (column, key) constants for the 32 keys of this half: lane & 31 = key (both lane halves write
+          // the same values); read back by this wave only -- a wave's LDS operations execute in order
+          const KeyW kw = kc[lq];
+          const float tx = jrx + (kw.b - (float)rg.ax0);
+          const float xf = floorf(tx);
+          CK e;
+          // masked key (padding, or not of this pass's group): taps in the kill column => P = 0, dS = 0
+          const bool dead = step * KT + kh * 32 + lq >= d.N || (gsel >= 0 && (kw.arow8 & 7) != gsel);
+          const float fx = tx - xf, fy = kw.fy;
+          if (dead) e.set(1.f, 0.f, 0.f, 0.f);
+          else e.set((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy, fx * (1.0f - fy), fx * fy);
+          e.cell = dead ? CAP * WIN_PITCH : (int)xf * WIN_PITCH + (kw.arow8 >> 3) + (sbh.amin - rg.ay0);   // arow8: relative to the half's first row
+          BEVR_ASSERT(dead || (e.cell >= 0 && e.cell + 32 + WIN_PITCH < L::WCOLS * WIN_PITCH));
+          pck[lq] = e;
+        }
+        Frag<PREC> kf, vkf, ktf;
+        kf.load(base + (kh * 32 + lq) * L::R_STRIDE, hi);
+        vkf.load(base + L::R_BYTES + (kh * 32 + lq) * L::R_STRIDE, hi);
+        load_perm(ktf, base + 2 * L::R_BYTES + lq * L::T_STRIDE + kh * 32 * EB, hi);
+
+        f32x16 s, dp;
+        {
+          // launder the row constants: otherwise the splatted 16-register accumulator seeds are hoisted out of the
+          // step loop and live in scratch (reloaded every step, a full-latency miss each time)
+          float nl = -lse, nd = -dlt;
+          asm volatile("" : "+v"(nl), "+v"(nd));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
+        }
+        if constexpr (PREC == BEVR_PREC_BF16) {
+          const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 2 * 64 + lane;
+          Frag<PREC> dos;
+          dos.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
+          dos.v[1] = __builtin_bit_cast(bf16x8, qd[64]);
+          s = mma_frag(kf, qf, s);        // S^T - LSE
+          dp = mma_frag(vkf, dos, dp);    // dP^T - delta
+        } else {
+          s = mma_frag(kf, qf, s);
+          dp = mma_frag(vkf, dof, dp);
+        }
+        PROF_TD(t2, s[0] + dp[15]);
+        PROF_ADD(1, t2 - t1);
+
+        {
+          // The LDS atomics are ordered memory operations for the compiler: it moves no load across them.  So
+          // the loop is software-pipelined by hand -- the taps of key r + 1 and the constants of key r + 2 are
+          // requested before the atomics of key r are issued, and their latency hides behind key r's arithmetic.
+          typedef typename std::conditional<PREC == BEVR_PREC_BF16, unsigned, f32x2>::type tap_t;
+          auto read_tap = [&](int cell, tap_t& a, tap_t& b) {
+            const char* p = win + (cell + lq) * ENT;
+            a = *reinterpret_cast<const tap_t*>(p);
+            b = *reinterpret_cast<const tap_t*>(p + WIN_PITCH * ENT);
+          };
+          const CK* pk = pck;
+          CK e0 = pk[crow(0, hi)], e1 = pk[crow(1, hi)];
+          tap_t ta, tb;
+          read_tap(e0.cell, ta, tb);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            tap_t na = ta, nb = tb;
+            CK e2 = e1;
+            if (r + 1 < 16) read_tap(e1.cell, na, nb);
+            if (r + 2 < 16) e2 = pk[crow(r + 2, hi)];
+            float sv;
+            if constexpr (PREC == BEVR_PREC_BF16) {
+              sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ta), __builtin_bit_cast(bf16x2, e0.wA), s[r],
+                                                   false);
+              sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, tb), __builtin_bit_cast(bf16x2, e0.wB), sv,
+                                                   false);
+            } else {
+              sv = fmaf(tb[1], e0.w11(), fmaf(tb[0], e0.w10(), fmaf(ta[1], e0.w01(), fmaf(ta[0], e0.w00(), s[r]))));
+            }
+            const float ds = fast_exp2(sv) * dp[r];   // masked keys: -1e30 from the kill column => 0
+            s[r] = ds;
+            // table gradient.  Table row (A + l) of column X receives  w00 dS[query l] + w01 dS[query l - 1]  (the
+            // upper tap of query l and the lower tap of the query above it); lane l adds exactly that, lane 31 the
+            // lower tap of query 30 alone (its own dS is 0), lane 0 / lane 32 get 0 from below (wave_shr zero fill /
+            // lane 31's zero).  One 64-bit fixed-point add per table column: order-free, bit-reproducible.
+            const float g = ds * gscale;
+            const float gb_ = lane_below(g);
+            float hA, hB;
+            if constexpr (PREC == BEVR_PREC_BF16) {   // the weights the bias was computed with; dS in bf16 as for dQ
+              const bf16x2 pr = __builtin_bit_cast(bf16x2, pack_bf16x2(g, gb_));
+              hA = __builtin_amdgcn_fdot2_f32_bf16(pr, __builtin_bit_cast(bf16x2, e0.wA), 0.f, false);
+              hB = __builtin_amdgcn_fdot2_f32_bf16(pr, __builtin_bit_cast(bf16x2, e0.wB), 0.f, false);
+            } else {
+              hA = fmaf(gb_, e0.w01(), g * e0.w00());
+              hB = fmaf(gb_, e0.w11(), g * e0.w10());
+            }
+            acc_t* gp = accw + (e0.cell + lq);
+            atomicAdd(gp, Acc::from(hA));
+            atomicAdd(gp + WIN_PITCH, Acc::from(hB));
+            e0 = e1; e1 = e2; ta = na; tb = nb;
+          }
+        }
+        PROF_TD(t3, s[15]);
+        PROF_ADD(2, t3 - t2);
+        dq = mma_acc_b(ktf, s, dq);
+        PROF_TD(t3b, dq[0]);
+        PROF_ADD(6, t3b - t3);
+      }
+
+      if (n_pass == 0 && sbh.amax >= sbh.amin) {
+        // ---- global-memory path: a half spread over more table than its groups can band (or a table so wide that
+        // no group fits a region).  Per-pair gathers from L2 and float atomics to HBM.
+        Frag<PREC> kf, vkf, ktf;
+        kf.load(base + (kh * 32 + lq) * L::R_STRIDE, hi);
+        vkf.load(base + L::R_BYTES + (kh * 32 + lq) * L::R_STRIDE, hi);
+        load_perm(ktf, base + 2 * L::R_BYTES + lq * L::T_STRIDE + kh * 32 * EB, hi);
+        f32x16 s, dp;
+        {
+          float nl = -lse, nd = -dlt;
+          asm volatile("" : "+v"(nl), "+v"(nd));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
+        }
+        if constexpr (PREC == BEVR_PREC_BF16) {
+          const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 2 * 64 + lane;
+          Frag<PREC> dos;
+          dos.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
+          dos.v[1] = __builtin_bit_cast(bf16x8, qd[64]);
+          s = mma_frag(kf, qf, s);
+          dp = mma_frag(vkf, dos, dp);
+        } else {
+          s = mma_frag(kf, qf, s);
+          dp = mma_frag(vkf, dof, dp);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const KeyW c = kc[crow(r, hi)];
@@ -442,12 +536,8 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
             atomicAdd(g0 + Hq + 1, w1 * c.fy);
           }
         }
+        dq = mma_acc_b(ktf, s, dq);
       }
-      PROF_TD(t3, s[15]);
-      PROF_ADD(2, t3 - t2);
-      dq = mma_acc_b(ktf, s, dq);
-      PROF_TD(t3b, dq[0]);
-      PROF_ADD(6, t3b - t3);
     }
 
     PROF_T(t4);
@@ -462,11 +552,11 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
     for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof[(wave ? 8 : 0) + i], pacc[i]);
   }
 #endif
-  flush_and_clear(rg, acc_live);
+  flush_and_clear(rg);
 
   // ---- store dQ (ln2 of dS = ln2 P (dP - delta) applied here) -----------------------------------------------
   if (live) {
-    float* row = dQ + ((size_t)ph * Mp + (size_t)jcol * d.Sp + i0 + lq) * 32;
+    float* row = dQ + ((size_t)ph * Mp + (size_t)jcol * d.Sp + qrow) * 32;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 v;
@@ -481,7 +571,7 @@ template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt, const void* V, const void* key_ws,
            const float* table_pair, const void* dO, const float* LSE, const float* delta,
            const float* grad_scale, float* dQ, float* dtable, hipStream_t st) {
-  const int n_rb = d.Sp / 32, n_cb = (d.S + NCOL - 1) / NCOL;
+  const int n_rb = (d.S + QROWS - 1) / QROWS, n_cb = (d.S + NCOL - 1) / NCOL;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_rb * n_cb;
   hipLaunchKernelGGL((attn_bwd_q_kernel<PREC>), dim3(grid), dim3(TQ), 0, st, d, (const char*)Q, (const char*)K,

@@ -31,7 +31,8 @@ __device__ __forceinline__ float wave_max_f(float v) {
 
 __global__ __launch_bounds__(256) void attn_keyprep_kernel(bevr_attn_desc d, const float* __restrict__ key_a,
                                                            const float* __restrict__ key_b, KeyW* __restrict__ kw_out,
-                                                           StepBox* __restrict__ box_out, int n_wave_total) {
+                                                           StepBox* __restrict__ box_out, StepBox* __restrict__ gbox_out,
+                                                           int n_wave_total) {
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);   // global wave = (prob * groups + grp) * n_step + step
   if (gw >= n_wave_total) return;
   const int lane = threadIdx.x & 63;
@@ -55,12 +56,33 @@ __global__ __launch_bounds__(256) void attn_keyprep_kernel(bevr_attn_desc d, con
   // dead (padded) keys: any in-window column (their logits are masked anyway); a half without any live key has no
   // box, so pin them to column 0 rather than to the reduction's identity
   k.b = live ? b : (amax >= amin ? bmin : 0.f);
-  k.arow8 = live ? (A - amin) * 8 : 0;
+  // groups of the half (attn_tile.h): row band x column band; only consulted when the half's own box fits no region
+  const float gwid = group_width(d);
+  const bool groupable = amax >= amin && amax - amin <= 63 && gwid >= 1.0f && (bmax - bmin) < 4.0f * gwid;
+  int gid = 0;
+  if (live && groupable) {
+    const int ga = (A - amin) >> 5;
+    const int gb = min(3, max(0, (int)floorf((b - bmin) / gwid)));
+    gid = ga * 4 + gb;
+  }
+  k.arow8 = live ? (A - amin) * 8 + gid : 0;
   kw_out[idx] = k;
   if ((lane & 31) == 0) {
     StepBox sb;
     sb.amin = amin; sb.amax = amax; sb.bmin = bmin; sb.bmax = bmax;
     box_out[2 * gw + (lane >> 5)] = sb;
+  }
+  StepBox* gb_half = gbox_out + (size_t)(2 * gw + (lane >> 5)) * N_GROUP;
+#pragma unroll
+  for (int g = 0; g < N_GROUP; ++g) {
+    const bool in = live && groupable && gid == g;
+    StepBox sb;
+    sb.amin = wave_min_i(in ? A : 0x7fffffff);
+    sb.amax = wave_max_i(in ? A : (int)0x80000000);
+    sb.bmin = wave_min_f(in ? b : 3.0e38f);
+    sb.bmax = wave_max_f(in ? b : -3.0e38f);
+    if (g == 0 && !groupable) { sb.amin = GROUPS_NONE; sb.amax = (int)0x80000000; }   // no groups: global path
+    if ((lane & 31) == 0) gb_half[g] = sb;
   }
 }
 
@@ -68,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_keyprep_kernel(bevr_attn_desc d, con
 
 extern "C" size_t bevr_attn_key_ws_bytes(const bevr_attn_desc* d) {
   if (bevr_check_desc(d)) return 0;
-  return key_ws_box_offset(*d) + (size_t)d->n_prob * d->groups * (d->Np / 32) * sizeof(StepBox);
+  return key_ws_gbox_offset(*d) + (size_t)d->n_prob * d->groups * (d->Np / 32) * N_GROUP * sizeof(StepBox);
 }
 
 extern "C" int bevr_attn_key_prep(const bevr_attn_desc* d, const float* key_a, const float* key_b, void* key_ws,
@@ -80,7 +102,8 @@ extern "C" int bevr_attn_key_prep(const bevr_attn_desc* d, const float* key_a, c
   const int n_wave = d->n_prob * d->groups * (d->Np / KT);
   KeyW* kw = reinterpret_cast<KeyW*>(key_ws);
   StepBox* box = reinterpret_cast<StepBox*>(reinterpret_cast<char*>(key_ws) + key_ws_box_offset(*d));
+  StepBox* gbox = reinterpret_cast<StepBox*>(reinterpret_cast<char*>(key_ws) + key_ws_gbox_offset(*d));
   hipLaunchKernelGGL(attn_keyprep_kernel, dim3((n_wave + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d, key_a, key_b,
-                     kw, box, n_wave);
+                     kw, box, gbox, n_wave);
   return (int)hipGetLastError();
 }

@@ -23,8 +23,19 @@ struct KeyW {
   int aoff;    // global path: byte offset ((A + y_off) + x_off * Hp) * 8 into the head's pair table
   float fy;    // frac(a)
   float b;     // clamped column coordinate
-  int arow8;   // window path: (A - Amin) * 8
+  int arow8;   // window path: (A - Amin of the key's 32-key half) * 8 + the key's group id within the half (0..7)
 };
+
+// Column capacity of the table regions, per precision mode and kernel (the LDS budgets are in the kernels).
+// The key-preparation kernel sizes the GROUPS of a half (below) for the smaller of the two.
+__host__ __device__ constexpr int region_cap_fwd(int prec) { return 88; }
+__host__ __device__ constexpr int region_cap_bwd_q(int prec) { return prec == BEVR_PREC_BF16 ? 56 : 48; }
+__host__ __device__ constexpr int region_cap_min(int prec) {
+  return region_cap_fwd(prec) < region_cap_bwd_q(prec) ? region_cap_fwd(prec) : region_cap_bwd_q(prec);
+}
+constexpr int QCOLS = 8;        // query columns per workgroup of the query-stationary kernels (one per wave)
+constexpr int N_GROUP = 8;      // groups per 32-key half: 2 row bands x 4 column bands
+constexpr int GROUPS_NONE = 0x7ffffffe;   // gbox[0].amin of a half that has no groups (distinct from an empty group's INT_MAX)
 
 struct WinInfo {
   int ok;       // window path valid for this step
@@ -43,10 +54,26 @@ struct StepBox {
 };
 
 // Byte layout of the key workspace handed between bevr_attn_key_prep and the query-stationary kernels:
-//   KeyW   [n_prob * groups][Np]        then
-//   StepBox[n_prob * groups][Np / 32]   one box per 32-key half of a step: the halves are windowed separately
+//   KeyW   [n_prob * groups][Np]                  then
+//   StepBox[n_prob * groups][Np / 32]             one box per 32-key half of a step, then
+//   StepBox[n_prob * groups][Np / 32][N_GROUP]    the boxes of the half's groups
+// Groups: a half whose box fits no region (its 32 keys are too far apart in table space: sparse far-field keys) is
+// not sent down the global-memory path any more (per-pair global gathers / float atomics: 1.5 % of the halves at cfg2
+// cost more than the other 98.5 % together).  Its keys are banded -- row band = (A - Amin) / 32, column band =
+// (b - bmin) / group_width -- and the kernels run one windowed pass per non-empty group with the other keys masked
+// (kill column).  Each group's box fits every region by construction (group_width below); a half spread over more
+// than 2 row bands or 4 column bands has no groups (gbox[0].amin = GROUPS_NONE marks it) and takes the global path.
 __host__ __device__ __forceinline__ size_t key_ws_box_offset(const bevr_attn_desc& d) {
   return (size_t)d.n_prob * d.groups * d.Np * sizeof(KeyW);
+}
+__host__ __device__ __forceinline__ size_t key_ws_gbox_offset(const bevr_attn_desc& d) {
+  return key_ws_box_offset(d) + (size_t)d.n_prob * d.groups * (d.Np / 32) * 16;
+}
+// widest spread of b a group may have so that its window fits `cap` columns for every 8-column query tile:
+// ncols = floor(jhi + bmax) + 2 - (floor(jlo + bmin) - 1) + 1 <= (QCOLS - 1) rx + (bmax - bmin) + 5
+__host__ __device__ __forceinline__ float group_width(const bevr_attn_desc& d) {
+  const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
+  return (float)region_cap_min(d.precision) - (float)(QCOLS - 1) * rx - 5.5f;
 }
 
 // Union of the two halves' boxes of a step (an empty half has amax < amin and huge bmin / -huge bmax: neutral).
@@ -81,8 +108,10 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 // with); f32 mode keeps them in full precision.
 template <int PREC> struct ColKeyT;
 template <> struct ColKeyT<BEVR_PREC_BF16> {
-  int cell;         // first tap's window position for lane row 0: cell index (backward) or byte offset (forward)
+  // member order: the weights are one aligned 8-byte read (ds_read_b64, 2 clk) and the cell one 4-byte read; with the
+  // cell first the compiler read the weights with ds_read2_b32 (4 clk)
   unsigned wA, wB;  // tap weights of column x / x + 1 as packed bf16x2 (row y, row y + 1)
+  int cell;         // first tap's window position for lane row 0: cell index (backward) or byte offset (forward)
   unsigned pad;
   __device__ __forceinline__ void set(float w00, float w01, float w10, float w11) {
     wA = pack_bf16x2(w00, w01);

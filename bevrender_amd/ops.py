@@ -273,7 +273,8 @@ class _AttnCore(torch.autograd.Function):
         dOe = dO.to(ed).contiguous()
         dev = dO.device
         d = geom.desc()
-        dQ = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
+        # zeros: bwd_q walks the grid in 31-row tiles and never visits the padded rows S..Sp-1 of a column
+        dQ = torch.zeros(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
         dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
         Kt = _perm_t(Ke)
         # fixed-point scale of the in-LDS table-gradient accumulation (include/bevrender_hip.h): a power of two s with

@@ -274,7 +274,7 @@ def test_key_prep_workspace_matches_numpy():
     a = (torch.rand(P, geom.Np, generator=g) * 3 - 1) * 2 * S          # exercises both clamps
     b = (torch.rand(P, geom.Np, generator=g) * 3 - 1) * Wt
     nbytes = L.bevr_attn_key_ws_bytes(C.byref(d))
-    assert nbytes == P * geom.Np * 16 + P * (geom.Np // 32) * 16
+    assert nbytes == P * geom.Np * 16 + P * (geom.Np // 32) * 16 * (1 + 8)    # KeyW, half boxes, 8 group boxes per half
     ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
     ad, bd = a.to(DEV).contiguous(), b.to(DEV).contiguous()
     rc = L.bevr_attn_key_prep(C.byref(d), C.c_void_p(ad.data_ptr()), C.c_void_p(bd.data_ptr()),
@@ -283,7 +283,8 @@ def test_key_prep_workspace_matches_numpy():
     torch.cuda.synchronize()
     raw = ws.cpu().numpy()
     kw = raw[:P * geom.Np * 16].view(np.int32).reshape(P, geom.Np, 4)
-    box = raw[P * geom.Np * 16:].view(np.int32).reshape(P, geom.Np // 32, 4)
+    box = raw[P * geom.Np * 16:P * geom.Np * 16 + P * (geom.Np // 32) * 16].view(np.int32).reshape(P, geom.Np // 32, 4)
+    gbox = raw[P * geom.Np * 16 + P * (geom.Np // 32) * 16:].view(np.int32).reshape(P, geom.Np // 32, 8, 4)
     an = np.clip(a.numpy(), -(geom.Sp + 1), geom.Ht + 1)
     bn = np.clip(b.numpy(), -(Wt // 2 + 2), Wt + 1)
     A = np.floor(an).astype(np.int64)
@@ -300,7 +301,20 @@ def test_key_prep_workspace_matches_numpy():
             amin, amax = A[p, sl][lv].min(), A[p, sl][lv].max()
             assert (box[p, h, 0], box[p, h, 1]) == (amin, amax)
             np.testing.assert_allclose(box[p, h, 2:].view(np.float32), [bn[p, sl][lv].min(), bn[p, sl][lv].max()], rtol=1e-6)
-            np.testing.assert_array_equal(kw[p, sl, 3][lv], (A[p, sl][lv] - amin) * 8)
+            np.testing.assert_array_equal(kw[p, sl, 3][lv] >> 3, A[p, sl][lv] - amin)
+            gid = kw[p, sl, 3][lv] & 7
+            if gbox[p, h, 0, 0] == 0x7ffffffe:                # no groups: the half is spread too far
+                assert (gid == 0).all()
+                continue
+            for g in range(8):                                 # every group's box is the box of its keys
+                m = gid == g
+                if not m.any():
+                    assert gbox[p, h, g, 1] < gbox[p, h, g, 0]
+                    continue
+                assert (gbox[p, h, g, 0], gbox[p, h, g, 1]) == (A[p, sl][lv][m].min(), A[p, sl][lv][m].max())
+                assert A[p, sl][lv][m].max() - A[p, sl][lv][m].min() <= 31
+                np.testing.assert_allclose(gbox[p, h, g, 2:].view(np.float32),
+                                           [bn[p, sl][lv][m].min(), bn[p, sl][lv][m].max()], rtol=1e-6)
             np.testing.assert_allclose(kw[p, sl, 2].view(np.float32)[lv], bn[p, sl][lv].astype(np.float32), rtol=1e-6)
 
 

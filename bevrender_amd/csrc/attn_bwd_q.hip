@@ -72,12 +72,12 @@ template <int PREC> struct LdsQ {
 
 constexpr int QROWS = 31;   // query rows per tile: lane 31 of each 32-lane half carries no query (see the kernel header)
 
-// round-to-nearest float -> int in one instruction (floor(x + 0.5))
-__device__ __forceinline__ int cvt_rpi(float x) {
-  int r;
-  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
+// round-to-nearest-even float -> int (v_rndne_f32 + v_cvt_i32_f32), as plain C so that the compiler sees the read.
+// Round 1 used inline asm (v_cvt_rpi_i32_f32, one instruction).  Inline asm is opaque to the hazard recognizer: fed
+// directly by a v_dot2c_f32_bf16 result (two instructions earlier in the stream) it read a stale register and the
+// bf16-mode table gradient came out 65 % wrong while the same arithmetic through v_fma_f32 was right
+// (tools/micro/dot2_test.hip shows the instruction itself is exact).
+__device__ __forceinline__ int cvt_rpi(float x) { return (int)__builtin_rintf(x); }
 
 // the value of the lane below (lane - 1) across the whole wave; lane 0 receives 0 (v_mov_b32_dpp wave_shr:1)
 __device__ __forceinline__ float lane_below(float x) {

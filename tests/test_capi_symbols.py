@@ -44,7 +44,7 @@ def test_argument_contract_is_checked_without_a_gpu():
     assert L.bevr_attn_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None) == -2
     assert L.bevr_sample_fwd(None, None, None, 1, 4, 4, 8, 4, None) == -1
     d.Np = 100032
-    assert L.bevr_attn_key_ws_bytes(ctypes.byref(d)) == 24 * 100032 * 16 + 24 * (100032 // 32) * 16
+    assert L.bevr_attn_key_ws_bytes(ctypes.byref(d)) == 24 * 100032 * 16 + 24 * (100032 // 32) * 16 * (1 + 8)
     assert L.bevr_attn_key_prep(ctypes.byref(d), None, None, None, None) == -1
     assert L.bevr_dwconv_fwd(None, None, None, None, 1, 4, 4, 8, 3, 1, 0, None) == -1
     one = ctypes.c_void_p(16)                                        # never dereferenced: the shape check comes first

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
     // if the whole step's box fits, both halves share one region test (fewer moves); else the halves go separately
     const WinInfo wi_step = make_wininfo(box_union(sb0, sb1), jrx_lo, jrx_hi, CAP);
     PROF_T(t1);
-    PROF_ADD(0, t1 - t0);
+    PROF_ADD(3, t1 - t0);   // staging store + barrier + box bookkeeping
     const KeyW* kc0 = reinterpret_cast<const KeyW*>(base + 2 * L::R_BYTES + L::T_BYTES);
 
 #pragma unroll 1
@@ -353,27 +353,41 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
           BEVR_ASSERT(wi.ok);
         }
         BEVR_ASSERT_WG_UNIFORM(wi.xlo * 131 + wi.amin * 7 + wi.ncols + gsel * 977);
+        PROF_T(tp);
         // ---- this pass's table window ------------------------------------------------------------------
         if (!region_contains(rg, wi, CAP)) {
           // every wave must be done with the taps and adds of the previous half / pass of this step
           if (kh || pass || moved_in_half) __syncthreads();
           flush_and_clear(rg);
           rg = region_anchor(wi, d, i0, CAP);
-          {   // fill the region: one wave-wide load per table column (lane = row)
+          {   // fill the region: one wave-wide load per table column (lane = row); all of a wave's loads are issued
+              // before the first LDS store (one L2 latency per move instead of one per column)
             const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
             BEVR_ASSERT(i0 + rg.ay0 + d.y_off >= 0 && i0 + rg.ay0 + d.y_off + WIN_PITCH <= d.Hp && rg.ax0 + d.x_off >= 0);
-            for (int c = wave; c < CAP; c += NWAVE) {
-              const f32x2 v = region_entry(tbl, d, rg, c, y0);
-              if constexpr (PREC == BEVR_PREC_BF16)
-                *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
-              else
-                *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = v;
+            constexpr int PER_WAVE = (CAP + NWAVE - 1) / NWAVE;
+            f32x2 fv[PER_WAVE];
+#pragma unroll
+            for (int k = 0; k < PER_WAVE; ++k) {
+              const int c = wave + k * NWAVE;
+              fv[k] = c < CAP ? region_entry(tbl, d, rg, c, y0) : f32x2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < PER_WAVE; ++k) {
+              const int c = wave + k * NWAVE;
+              if (c < CAP) {
+                if constexpr (PREC == BEVR_PREC_BF16)
+                  *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(fv[k][0], fv[k][1]);
+                else
+                  *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = fv[k];
+              }
             }
           }
           moved_in_half = true;
           __syncthreads();
           PROF_ADD(5, 1);
         }
+        PROF_T(tq);
+        PROF_ADD(0, tq - tp);   // region handling (moves: flush + refill + barriers)
         {   // the pass's cells become dirty (region coordinates)
           dc0 = min(dc0, wi.xlo - rg.ax0);
           dc1 = max(dc1, wi.xlo - rg.ax0 + wi.ncols - 1);
@@ -396,11 +410,8 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
           BEVR_ASSERT(dead || (e.cell >= 0 && e.cell + 32 + WIN_PITCH < L::WCOLS * WIN_PITCH));
           pck[lq] = e;
         }
-        Frag<PREC> kf, vkf, ktf;
-        kf.load(base + (kh * 32 + lq) * L::R_STRIDE, hi);
-        vkf.load(base + L::R_BYTES + (kh * 32 + lq) * L::R_STRIDE, hi);
-        load_perm(ktf, base + 2 * L::R_BYTES + lq * L::T_STRIDE + kh * 32 * EB, hi);
-
+        // operand fragments are loaded one MFMA chain at a time (K with Q, then V with dO; K^T only after the loop):
+        // all three at once put the kernel 16 registers over its 128 and the Q fragment went to scratch
         f32x16 s, dp;
         {
           // launder the row constants: otherwise the splatted 16-register accumulator seeds are hoisted out of the
@@ -410,19 +421,26 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
         }
-        if constexpr (PREC == BEVR_PREC_BF16) {
-          const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 2 * 64 + lane;
-          Frag<PREC> dos;
-          dos.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
-          dos.v[1] = __builtin_bit_cast(bf16x8, qd[64]);
+        {
+          Frag<PREC> kf;
+          kf.load(base + (kh * 32 + lq) * L::R_STRIDE, hi);
           s = mma_frag(kf, qf, s);        // S^T - LSE
-          dp = mma_frag(vkf, dos, dp);    // dP^T - delta
-        } else {
-          s = mma_frag(kf, qf, s);
-          dp = mma_frag(vkf, dof, dp);
+        }
+        {
+          Frag<PREC> vkf;
+          vkf.load(base + L::R_BYTES + (kh * 32 + lq) * L::R_STRIDE, hi);
+          if constexpr (PREC == BEVR_PREC_BF16) {
+            const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 2 * 64 + lane;
+            Frag<PREC> dos;
+            dos.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
+            dos.v[1] = __builtin_bit_cast(bf16x8, qd[64]);
+            dp = mma_frag(vkf, dos, dp);    // dP^T - delta
+          } else {
+            dp = mma_frag(vkf, dof, dp);
+          }
         }
         PROF_TD(t2, s[0] + dp[15]);
-        PROF_ADD(1, t2 - t1);
+        PROF_ADD(1, t2 - tq);
 
         {
           // The LDS atomics are ordered memory operations for the compiler: it moves no load across them.  So
@@ -478,7 +496,11 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
         }
         PROF_TD(t3, s[15]);
         PROF_ADD(2, t3 - t2);
-        dq = mma_acc_b(ktf, s, dq);
+        {
+          Frag<PREC> ktf;
+          load_perm(ktf, base + 2 * L::R_BYTES + lq * L::T_STRIDE + kh * 32 * EB, hi);
+          dq = mma_acc_b(ktf, s, dq);
+        }
         PROF_TD(t3b, dq[0]);
         PROF_ADD(6, t3b - t3);
       }
@@ -543,7 +565,6 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
     PROF_T(t4);
     __syncthreads();   // every wave is done with the staged tiles (and with the region, should the next step move it)
     PROF_T(t5);
-    PROF_ADD(3, t4 - t1);
     PROF_ADD(4, t5 - t4);
     PROF_ADD(7, 1);
   }

@@ -190,12 +190,19 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       // fill the region: one wave-wide load per table column (lane = row)
       const size_t y0 = (size_t)(i0 + rg.ay0 + d.y_off) + lane;
       BEVR_ASSERT(i0 + rg.ay0 + d.y_off >= 0 && i0 + rg.ay0 + d.y_off + WIN_PITCH <= d.Hp && rg.ax0 + d.x_off >= 0);
-      for (int c = wave; c < WIN_COLS; c += NWF) {
-        const f32x2 v = region_entry(tbl, d, rg, c, y0);
+      // all of a wave's loads are issued before the first LDS store: one L2 latency per move, not one per column
+      constexpr int PER_WAVE = WIN_COLS / NWF;
+      static_assert(PER_WAVE * NWF == WIN_COLS, "region columns are dealt evenly over the waves");
+      f32x2 fv[PER_WAVE];
+#pragma unroll
+      for (int k = 0; k < PER_WAVE; ++k) fv[k] = region_entry(tbl, d, rg, wave + k * NWF, y0);
+#pragma unroll
+      for (int k = 0; k < PER_WAVE; ++k) {
+        const int c = wave + k * NWF;
         if constexpr (PREC == BEVR_PREC_BF16)
-          *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(v[0], v[1]);
+          *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(fv[k][0], fv[k][1]);
         else
-          *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = v;
+          *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = fv[k];
       }
       __syncthreads();
     };

@@ -61,27 +61,45 @@ __global__ __launch_bounds__(256) void sample_fwd_kernel(const float* __restrict
   }
 }
 
-// One key per group of G = C/4 lanes (G a power of two <= 64 is reduced with shuffles; otherwise the
+// Backward.  One key per group of G = C/4 lanes (G a power of two <= 64 is reduced with shuffles; otherwise the
 // position gradient is added with atomics per thread).
-__global__ __launch_bounds__(256) void sample_bwd_kernel(const float* __restrict__ feat,
-                                                         const float* __restrict__ pos,
-                                                         const float* __restrict__ dout,
-                                                         float* __restrict__ dfeat, float* __restrict__ dpos,
-                                                         int nb, int Hi, int Wi, int C, int N, int pow2_group) {
+//
+// The feature gradient is a scatter of 4 contiguous C*4-byte runs per key (float atomics; contiguous 256-B shapes run
+// at the full atomic rate).  One pattern does not: the projector pins every pillar point that falls outside a
+// camera's image to pixel (0, 0) (model/bev_cmr_proj.py:76), so at the benchmark rig 66 % of the 100 000 keys of a
+// view land, give or take the learned offset, on the same ~6 pixels of the feature map's top-left corner -- every
+// workgroup's atomics on one 256-B row, the shape MI355X_MICROARCH.md measures 14x slower (17 ms per launch at B = 4).
+// So the top-left HOT_R x HOT_C pixels are not scattered per key: each thread sums what its keys contribute to them
+// in registers (the 2x2 tap weights as an outer product wy[row] * wx[col], no data-dependent register index), the
+// workgroup reduces those sums over its 16 key slots through LDS, and ONE atomic per (hot pixel, channel) leaves the
+// workgroup.  A workgroup stays inside one image so that the sums stay separable.
+constexpr int HOT_R = 4, HOT_C = 2, SB_THREADS = 256;
+
+template <bool HOT>
+__global__ __launch_bounds__(SB_THREADS) void sample_bwd_kernel(const float* __restrict__ feat,
+                                                                const float* __restrict__ pos,
+                                                                const float* __restrict__ dout,
+                                                                float* __restrict__ dfeat, float* __restrict__ dpos,
+                                                                int nb, int Hi, int Wi, int C, int N, int pow2_group) {
+  __shared__ float red[HOT ? SB_THREADS * HOT_R * HOT_C * 4 : 1];
   const int c4n = C >> 2;
-  const long long total = (long long)nb * N * c4n;
+  const int b = blockIdx.y;                       // one image per workgroup row
+  const long long per_img = (long long)N * c4n;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  // total is padded up so that whole waves stay converged for the shuffles
-  const long long padded = (total + 63) / 64 * 64;
+  // padded up so that whole waves stay converged for the shuffles
+  const long long padded = (per_img + 63) / 64 * 64;
+  f32x4 hot[HOT ? HOT_R * HOT_C : 1];
+#pragma unroll
+  for (int p = 0; p < (HOT ? HOT_R * HOT_C : 1); ++p) hot[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const size_t img = (size_t)b * Hi * Wi * C;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < padded; idx += stride) {
-    const bool live = idx < total;
-    const long long id = live ? idx : total - 1;
+    const bool live = idx < per_img;
+    const long long id = live ? idx : per_img - 1;
     const int c4 = (int)(id % c4n);
-    const long long kn = id / c4n;
-    const int b = (int)(kn / N);
+    const long long kn = (long long)b * N + id / c4n;
     const f32x2 p = *reinterpret_cast<const f32x2*>(pos + kn * 2);
     const Taps t = make_taps(p[0], p[1], Hi, Wi);
-    const size_t fo = (size_t)b * Hi * Wi * C + c4 * 4;
+    const size_t fo = img + c4 * 4;
     const float* fb = feat + fo;
     float* gb = dfeat + fo;
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -94,13 +112,32 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(const float* __restrict
     f32x4 v11 = b11 ? *reinterpret_cast<const f32x4*>(fb + o11) : z;
     const float w00 = (1.f - t.fx) * (1.f - t.fy), w01 = t.fx * (1.f - t.fy);
     const float w10 = (1.f - t.fx) * t.fy, w11 = t.fx * t.fy;
+    // which taps fall on the hot corner (those are summed in registers, the others scattered)
+    bool h00 = false, h01 = false, h10 = false, h11 = false;
+    if (HOT) {
+      const bool ry0 = t.y0 >= 0 && t.y0 < HOT_R, ry1 = t.y0 + 1 >= 0 && t.y0 + 1 < HOT_R;
+      const bool cx0 = t.x0 >= 0 && t.x0 < HOT_C, cx1 = t.x0 + 1 >= 0 && t.x0 + 1 < HOT_C;
+      h00 = ry0 && cx0; h01 = ry0 && cx1; h10 = ry1 && cx0; h11 = ry1 && cx1;
+      if (live) {
+        // weight of hot pixel (r, c) for this key = wy[r] * wx[c]: the tap rows / columns it coincides with
+#pragma unroll
+        for (int r = 0; r < HOT_R; ++r) {
+          const float wy = (t.y0 == r ? 1.f - t.fy : 0.f) + (t.y0 + 1 == r ? t.fy : 0.f);
+#pragma unroll
+          for (int c = 0; c < HOT_C; ++c) {
+            const float wx = (t.x0 == c ? 1.f - t.fx : 0.f) + (t.x0 + 1 == c ? t.fx : 0.f);
+            hot[r * HOT_C + c] += g * (wy * wx);
+          }
+        }
+      }
+    }
     if (live) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (b00) atomicAdd(gb + o00 + k, g[k] * w00);
-        if (b01) atomicAdd(gb + o01 + k, g[k] * w01);
-        if (b10) atomicAdd(gb + o10 + k, g[k] * w10);
-        if (b11) atomicAdd(gb + o11 + k, g[k] * w11);
+        if (b00 && !h00) atomicAdd(gb + o00 + k, g[k] * w00);
+        if (b01 && !h01) atomicAdd(gb + o01 + k, g[k] * w01);
+        if (b10 && !h10) atomicAdd(gb + o10 + k, g[k] * w10);
+        if (b11 && !h11) atomicAdd(gb + o11 + k, g[k] * w11);
       }
     }
     // d out / d ix = (v01 - v00)(1 - fy) + (v11 - v10) fy ; d out / d iy = (v10 - v00)(1 - fx) + (v11 - v01) fx
@@ -124,6 +161,28 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(const float* __restrict
     } else if (live) {
       atomicAdd(dpos + kn * 2, gy);
       atomicAdd(dpos + kn * 2 + 1, gx);
+    }
+  }
+  if (HOT) {
+    // HOT requires c4n | SB_THREADS (checked by the launcher): a thread keeps its channel quad c4 = tid % c4n over
+    // the whole grid-stride loop, and the SB_THREADS / c4n threads that share a c4 are reduced here.
+    const int tid = threadIdx.x;
+    constexpr int NP = HOT_R * HOT_C;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(red + ((size_t)p * SB_THREADS + tid) * 4) = hot[p];
+    __syncthreads();
+    const int slots = SB_THREADS / c4n;
+    // (pixel p, channel quad c4): c4n * NP sums of `slots` partials each, dealt over the threads
+    for (int u = tid; u < NP * c4n; u += SB_THREADS) {
+      const int p = u / c4n, c4 = u % c4n;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      for (int sl = 0; sl < slots; ++sl) a += *reinterpret_cast<const f32x4*>(red + ((size_t)p * SB_THREADS + sl * c4n + c4) * 4);
+      const int r = p / HOT_C, c = p % HOT_C;
+      if (r < Hi && c < Wi && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f || a[3] != 0.f)) {
+        float* gp = dfeat + img + ((size_t)r * Wi + c) * C + c4 * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(gp + k, a[k]);
+      }
     }
   }
 }
@@ -161,8 +220,19 @@ extern "C" int bevr_sample_bwd(const float* feat, const float* pos, const float*
     hipError_t e = hipMemsetAsync(dpos, 0, (size_t)nb * N * 2 * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
-  long long total = (long long)nb * N * c4n;
-  hipLaunchKernelGGL(sample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, feat, pos, dout,
-                     dfeat, dpos, nb, Hi, Wi, C, N, pow2);
+  // one image per workgroup row; enough workgroups per image to fill the chip, few enough that the per-workgroup
+  // reduction of the hot corner is amortised over >= 64 keys per thread slot
+  const long long per_img = (long long)N * c4n;
+  long long gx = (per_img + SB_THREADS - 1) / SB_THREADS;
+  const long long want = (256LL * 16 + nb - 1) / nb;
+  if (gx > want) gx = want;
+  if (gx < 1) gx = 1;
+  const bool hot = (SB_THREADS % c4n) == 0;
+  if (hot)
+    hipLaunchKernelGGL((sample_bwd_kernel<true>), dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream, feat,
+                       pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, pow2);
+  else
+    hipLaunchKernelGGL((sample_bwd_kernel<false>), dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream, feat,
+                       pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, pow2);
   return (int)hipGetLastError();
 }

@@ -198,22 +198,27 @@ class _KernelTimer:
         self.on = False
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1 in self.records:
-            r = out.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0})
-            r["ms"] += e0.elapsed_time(e1)
+        for name, flops, nbytes, e0, e1 in self.records:
+            r = out.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "max_ms": 0.0})
+            ms = e0.elapsed_time(e1)
+            r["ms"] += ms
+            r["max_ms"] = max(r["max_ms"], ms)
             r["n"] += 1
             r["flops"] += flops
+            r["bytes"] += nbytes
         self.records = []
         return out
 
-    def run(self, name, flops, fn, *args):
+    def run(self, name, flops, fn, *args, nbytes=0.0):
+        """flops / nbytes: the launch's ALGORITHMIC work (MFMA flops of an attention launch; HBM bytes of a sampling
+        launch), for the roofline lines of bench.py."""
         if not self.on:
             return fn(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)
         e1.record()
-        self.records.append((name, flops, e0, e1))
+        self.records.append((name, flops, nbytes, e0, e1))
         return rc
 
 
@@ -338,8 +343,10 @@ class _Sample(torch.autograd.Function):
         nb, Hi, Wi, Cc = feat.shape
         N = pos.shape[1]
         out = torch.empty(nb, N, Cc, device=feat.device, dtype=torch.float32)
+        # algorithmic HBM bytes: 4 taps read + 1 row written per key, C floats each
         _lib.check(KERNEL_TIMER.run("bevr_sample_fwd", 0.0, _lib.lib().bevr_sample_fwd, _ptr(feat), _ptr(pos),
-                                    _ptr(out), nb, Hi, Wi, Cc, N, _stream()), "bevr_sample_fwd")
+                                    _ptr(out), nb, Hi, Wi, Cc, N, _stream(), nbytes=5.0 * nb * N * Cc * 4),
+                   "bevr_sample_fwd")
         ctx.save_for_backward(feat, pos)
         return out
 
@@ -351,9 +358,10 @@ class _Sample(torch.autograd.Function):
         dout = dout.contiguous()
         dfeat = torch.zeros_like(feat)
         dpos = torch.empty_like(pos)
+        # algorithmic HBM bytes: dout row + 4 taps read (position gradient) + 4 taps scattered, C floats each
         _lib.check(KERNEL_TIMER.run("bevr_sample_bwd", 0.0, _lib.lib().bevr_sample_bwd, _ptr(feat), _ptr(pos),
-                                    _ptr(dout), _ptr(dfeat), _ptr(dpos), nb, Hi, Wi, Cc, N, _stream()),
-                   "bevr_sample_bwd")
+                                    _ptr(dout), _ptr(dfeat), _ptr(dpos), nb, Hi, Wi, Cc, N, _stream(),
+                                    nbytes=9.0 * nb * N * Cc * 4), "bevr_sample_bwd")
         return dfeat, dpos
 
 

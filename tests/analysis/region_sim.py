@@ -92,3 +92,47 @@ def walk(cap, ncol=8, rows_max=63):
 for cap in (40, 48, 52, 56, 64, 88):
     f, m, w = walk(cap)
     print(f"CAP {cap:3d} columns: halves served from the LDS region {f:.4f}; region moves per step {m:.3f}; whole-step windows {w:.3f}")
+
+
+# ---- look-ahead anchoring: on a move, centre the region on the union of the longest run of following boxes that
+# still fits (instead of on the box that forced the move) -------------------------------------------------------------
+def walk_lookahead(cap, ncol=8, rows_max=63, max_run=64):
+    tot = moves = 0
+    for v in range(V):
+        A = np.floor(a_all[v]).astype(int)
+        b = b_all[v]
+        nh = N // 32
+        amin = A[:nh * 32].reshape(nh, 32).min(1); amax = A[:nh * 32].reshape(nh, 32).max(1)
+        bmin = b[:nh * 32].reshape(nh, 32).min(1); bmax = b[:nh * 32].reshape(nh, 32).max(1)
+        wb = cap - (ncol - 1) * rx - 5.5
+        for cb in range(0, S // ncol, 6):
+            jlo, jhi = cb * ncol * rx, (cb * ncol + ncol - 1) * rx
+            rg = None
+
+            def info(lo_a, hi_a, lo_b, hi_b):
+                nrows = 32 + hi_a - lo_a
+                xlo = int(math.floor(jlo + lo_b)) - 1
+                xhi = int(math.floor(jhi + hi_b)) + 2
+                return lo_a, nrows, xlo, xhi - xlo + 1, (nrows <= rows_max and xhi - xlo + 1 <= cap)
+
+            for s in range(nh):
+                wi = info(amin[s], amax[s], bmin[s], bmax[s])
+                if not wi[4]:
+                    continue                                  # grouped / fallback: not modelled here
+                tot += 1
+                if rg is not None and wi[2] >= rg[0] and wi[2] + wi[3] <= rg[0] + cap and wi[0] >= rg[1] and wi[0] + wi[1] <= rg[1] + rows_max:
+                    continue
+                moves += 1
+                la, ha, lb, hb = amin[s], amax[s], bmin[s], bmax[s]
+                for t in range(s + 1, min(nh, s + max_run)):
+                    na, xa, nb, xb = min(la, amin[t]), max(ha, amax[t]), min(lb, bmin[t]), max(hb, bmax[t])
+                    if xa - na > 31 or xb - nb > wb:
+                        break
+                    la, ha, lb, hb = na, xa, nb, xb
+                u = info(la, ha, lb, hb)
+                rg = (u[2] - (cap - u[3]) // 2, u[0] - (rows_max - u[1]) // 2)
+    return moves / (tot / 2)
+
+
+for cap in (56, 64, 88):
+    print(f"CAP {cap:3d} look-ahead anchoring: region moves per step {walk_lookahead(cap):.3f}")

@@ -12,7 +12,7 @@ os.environ["ITERS"] = "1"
 exec(open(os.path.join(ROOT, "tools", "prof_sca.py")).read())
 torch.cuda.synchronize()
 L.bevr_debug_prof(buf, 0)
-names = ["top(region)", "frag+mfma", "r-loop", "body", "barrier", "n_region", "dq-mfma", "n_step"]
+names = ["region", "consts+frag+mfma", "r-loop", "stage+barrier", "end-barrier", "n_region", "dq-mfma", "n_step"]
 for w in (0, 1):
     v = list(buf[8 * w: 8 * w + 8])
     n = max(v[7], 1)

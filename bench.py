@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Headline benchmark: samples/s, forward+backward, of the BEV-lift + correlation hot path.
 
-Workload (BASELINE.json configs[1] + the correlation head of configs[2]):
+Workload (BASELINE.json configs[2] = configs[1] + the correlation head):
   per sample: T=2 frames x V=6 cameras of 256x704 backbone FEATURES (stride 4: 64 x 64 x 176, synthetic
   N(0,1), generated in bf16) through L=2 encoder layers (LPU conv, LN, TSA, MLP, LPU, SCA, MLP) on a
   200x200 BEV grid, C=64, 2 heads, D=5 height bins; frame 0 forward-only/no-grad (history BEV), frame 1
-  forward+backward; loss = contrastive ground<->aerial correlation of the flattened BEV against a synthetic
-  aerial embedding + a mean-square render proxy; AdamW step.  Batch 4 per GPU, data parallel over N GPUs
-  (one process per GPU, gradient all-reduce over RCCL, weak scaling).  The image backbone and render CNN
-  are outside the path (left to MIOpen) and are not run.
+  forward+backward; loss = contrastive + lifted-structure ground<->aerial correlation of the flattened BEV
+  against a synthetic aerial embedding + a mean-square render proxy; AdamW step.  Batch 8 per GPU (config 3;
+  `--batch 4` is config 2's batch), data parallel over N GPUs (one process per GPU, gradient all-reduce over
+  RCCL, weak scaling).  The image backbone and render CNN are outside the path (left to MIOpen) and are not run.
 
 Prints ONE JSON line (rank 0).  `python bench.py --gpus N --steps K --warmup W`.  For N > 1 either launch it under
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU; RANK / LOCAL_RANK /
@@ -57,6 +57,7 @@ class LiftBlock(nn.Module):
         from bevrender_amd.model.bev_cmr_proj import BEV2CameraProjector
         from bevrender_amd.model.encoder import EncoderLayer
         from bevrender_amd.loss.contrastive_loss import ContrastiveLoss
+        from bevrender_amd.loss.lift_loss import LiftedStructureLoss
         T, K = ring_rig(V, img_w, img_h)
         proj = BEV2CameraProjector(imu_to_rgb={0: T}, K={0: K}, vehicle_type_code=0, img_width=img_w, img_height=img_h,
                                    ori_img_width=img_w, ori_img_height=img_h, device=device)
@@ -68,6 +69,7 @@ class LiftBlock(nn.Module):
         self.bev_embedding = nn.Embedding(S * S, C)
         self.S, self.C = S, C
         self.loss = ContrastiveLoss()
+        self.lift = LiftedStructureLoss()
         # reference init (model/bevrender.py:152-172)
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -94,7 +96,8 @@ class LiftBlock(nn.Module):
         with torch.no_grad():
             prev = self.encode(feats_hist, None)
         bev = self.encode(feats_cur, prev)
-        corr = self.loss.get_loss(bev.flatten(1), map_emb)
+        emb = bev.flatten(1)
+        corr = self.loss.get_loss(emb, map_emb) + self.lift.get_loss(emb, map_emb)   # config 3: contrastive + lifted
         return corr + bev.square().mean()
 
 
@@ -105,12 +108,46 @@ def attn_flops(kind, geom):
     return 2.0 * 32 * pairs * n_mm
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The oracle (CPU restatement of the reference, materialised formulation) on the host cores:
-    the same unit of work (L=2 layers, T=2 frames, V=6 views, fwd+bwd on the last frame) at a BEV side the
-    materialised (M x N) tensors fit in host RAM."""
+def _oracle_params(C, h, D, V, S):
+    """Random parameters of one EncoderLayer under the reference's state_dict names (oracle.encoder_layer_forward)."""
+    p = {}
+
+    def conv(name, co, ci, k, bias=True):
+        p[name + ".weight"] = (torch.randn(co, ci, k, k) / math.sqrt(ci * k * k)).requires_grad_(True)
+        if bias:
+            p[name + ".bias"] = torch.zeros(co, requires_grad=True)
+
+    def ln(name, c):
+        p[name + ".norm.weight"] = torch.ones(c, requires_grad=True)
+        p[name + ".norm.bias"] = torch.zeros(c, requires_grad=True)
+
+    ln("layer_norm", C)
+    for mlp in ("tsa_mlp", "sca_mlp"):
+        conv(mlp + ".linear1.0", 4 * C, C, 1); conv(mlp + ".linear2.0", C, 4 * C, 1); conv(mlp + ".dwc", 4 * C, 1, 3)
+    conv("tsa_local_percept_unit", C, 1, 3); conv("sca_local_percept_unit", C, 1, 3)
+    t = "temporal_self_attn.temporal_deform_attn."
+    conv(t + "conv_offset.0", C, 1, 3); ln(t + "conv_offset.1", C); conv(t + "conv_offset.3", 2, C, 1, False)
+    sp = "spatial_cross_attn.spatial_deform_attn."
+    for v in range(V):
+        conv(sp + f"conv_offset_m{v}.0", C * D, 1, 1); ln(sp + f"conv_offset_m{v}.1", C * D)
+        conv(sp + f"conv_offset_m{v}.3", D, C * D, 1, False)
+    for pre in (t, sp):
+        conv(pre + "proj_k", C, C, 1); conv(pre + "proj_v", C, C, 1)
+    conv(t + "proj_out", C, C, 1); conv(sp + "proj_out", C, V * C, 1)
+    p[t + "rpe_table"] = (torch.randn(h, 2 * S - 1, 2 * S - 1) * 0.01).requires_grad_(True)
+    p[sp + "rpe_table"] = (torch.randn(h, 2 * S - 1, 2 * S * D - 1) * 0.01).requires_grad_(True)
+    return p
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """The oracle (CPU restatement of the reference, its materialised M x N formulation, fp32) on the host cores of
+    this box, on the unit of work the GPU number counts (per sample: L=2 encoder layers, T=2 frames, fwd+bwd on the
+    last frame), as SURVEY.md section 8d specifies:
+      value : BASELINE config 1 exactly -- 1 camera, 128x128 image (16x16 features), 50x50 BEV;
+      cfg2_geometry_s56 : config 2's geometry (6-camera ring, 64x176 features) at the largest BEV side whose
+          materialised tensors fit host memory in reasonable time (S=56), one layer timed forward and
+          forward+backward, assembled into the per-sample time and EXTRAPOLATED to S=200 by the M*N ratio (labelled)."""
     from oracle import bevrender_oracle as O
-    S, C, h, D, V, L = 28, 64, 2, 5, 6, 2
     torch.manual_seed(15213)
     # the threads this process may actually use: a GPU box hands one GPU's job a 16-core share of a much
     # larger host, and os.cpu_count() would oversubscribe it by an order of magnitude
@@ -120,68 +157,70 @@ def cpu_baseline(seconds_budget=20.0):
         avail = os.cpu_count() or 1
     cores = int(os.environ.get("BEVR_CPU_THREADS", min(avail, 16)))
     torch.set_num_threads(cores)
+    C, h, D, L = 64, 2, 5, 2
 
-    def mk_params():
-        p = {}
-        def conv(name, co, ci, k, bias=True):
-            p[name + ".weight"] = (torch.randn(co, ci, k, k) / math.sqrt(ci * k * k)).requires_grad_(True)
-            if bias:
-                p[name + ".bias"] = torch.zeros(co, requires_grad=True)
-        def ln(name, c):
-            p[name + ".norm.weight"] = torch.ones(c, requires_grad=True)
-            p[name + ".norm.bias"] = torch.zeros(c, requires_grad=True)
-        ln("layer_norm", C)
-        for mlp in ("tsa_mlp", "sca_mlp"):
-            conv(mlp + ".linear1.0", 4 * C, C, 1); conv(mlp + ".linear2.0", C, 4 * C, 1); conv(mlp + ".dwc", 4 * C, 1, 3)
-        conv("tsa_local_percept_unit", C, 1, 3); conv("sca_local_percept_unit", C, 1, 3)
-        t = "temporal_self_attn.temporal_deform_attn."
-        conv(t + "conv_offset.0", C, 1, 3); ln(t + "conv_offset.1", C); conv(t + "conv_offset.3", 2, C, 1, False)
-        s = "spatial_cross_attn.spatial_deform_attn."
-        for v in range(V):
-            conv(s + f"conv_offset_m{v}.0", C * D, 1, 1); ln(s + f"conv_offset_m{v}.1", C * D)
-            conv(s + f"conv_offset_m{v}.3", D, C * D, 1, False)
-        for pre, cin in ((t, C), (s, C)):
-            conv(pre + "proj_k", C, C, 1); conv(pre + "proj_v", C, C, 1)
-        conv(t + "proj_out", C, C, 1); conv(s + "proj_out", C, V * C, 1)
-        p[t + "rpe_table"] = (torch.randn(h, 2 * S - 1, 2 * S - 1) * 0.01).requires_grad_(True)
-        p[s + "rpe_table"] = (torch.randn(h, 2 * S - 1, 2 * S * D - 1) * 0.01).requires_grad_(True)
-        return p
+    def layer_fn(S, V, T, K, img_w, img_h, Hi, Wi, bound):
+        params = [_oracle_params(C, h, D, V, S) for _ in range(L)]
+        pts = O.sample_3d_points(bound, S, D, -1.0)
+        ref = O.sca_reference_points(O.bev_grid_to_camera(pts, T, K, img_w, img_h, img_w, img_h), 1)
+        q0 = torch.rand(1, C, S, S)
+        feats = [torch.randn(V, C, Hi, Wi) for _ in range(2)]
 
-    params = [mk_params() for _ in range(L)]
-    T, K = ring_rig(V, 704, 256)
-    pts = O.sample_3d_points({"X": 50, "Y": 50, "Z": 2}, S, D, -1.0)
-    ref = O.sca_reference_points(O.bev_grid_to_camera(pts, T, K, 704, 256, 704, 256), 1)
-    q0 = torch.rand(1, C, S, S)
-    feats = [torch.randn(V, C, 64, 176) for _ in range(2)]
+        def run(x, f, prev, n_layers=L):
+            for p in params[:n_layers]:
+                x = O.encoder_layer_forward(p, x, f, prev, ref, n_heads=h, n_groups=1, depth_dim=D, n_views=V,
+                                            kernel_size=3, stride=1)
+            return x
+        return run, q0, feats
 
-    def run(x, f, prev):
-        for p in params:
-            x = O.encoder_layer_forward(p, x, f, prev, ref, n_heads=h, n_groups=1, depth_dim=D, n_views=V,
-                                        kernel_size=3, stride=1)
-        return x
+    # ---- config 1 exactly ------------------------------------------------------------------------------
+    T1 = np.eye(4); T1[:3, :3] = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=np.float64); T1[:3, 3] = (0, 0, 1.5)
+    K1 = np.array([[100, 0, 64, 0], [0, 100, 64, 0], [0, 0, 1, 0]], dtype=np.float64)
+    run1, q1, f1 = layer_fn(50, 1, [T1], [K1], 128, 128, 16, 16, {"X": 20, "Y": 10, "Z": 2})
 
     def one_sample():
         with torch.no_grad():
-            prev = run(q0, feats[0], None)
-        out = run(q0, feats[1], prev)
-        out.square().mean().backward()
+            prev = run1(q1, f1[0], None)
+        run1(q1, f1[1], prev).square().mean().backward()
 
     t_w = time.perf_counter()
     one_sample()  # warm-up (allocator, thread pool)
-    print(f"[bench] cpu_baseline warm-up sample: {time.perf_counter() - t_w:.1f} s on {cores} threads",
+    print(f"[bench] cpu_baseline cfg1 warm-up sample: {time.perf_counter() - t_w:.1f} s on {cores} threads",
           file=sys.stderr, flush=True)
     n, t0 = 0, time.perf_counter()
     while True:
         one_sample()
         n += 1
         dt = time.perf_counter() - t0
-        print(f"[bench] cpu_baseline: {n} samples, {dt:.1f} s", file=sys.stderr, flush=True)
         if dt > seconds_budget or n >= 50:
             break
-    return {"value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (CPU restatement, materialised MxN formulation, fp32) on the same unit of work at "
-                      f"BEV side S={S} (M=784, N_sca=1960 per view; cfg2 is S=200 with 2600x more query-key pairs), "
-                      f"V=6, L=2, T=2, fwd+bwd, {n} samples in {dt:.1f} s; NOT extrapolated"}
+    print(f"[bench] cpu_baseline cfg1: {n} samples, {dt:.1f} s", file=sys.stderr, flush=True)
+    out = {"value": n / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"oracle (CPU restatement of the reference, materialised MxN formulation, fp32) on BASELINE config 1 "
+                     f"exactly: 1 camera, 128x128 image (16x16 features), 50x50 BEV (M=2500, N_tsa=2500, N_sca=6250), "
+                     f"L=2, T=2, fwd+bwd; {n} samples in {dt:.1f} s"}
+
+    # ---- config 2's geometry at S=56, one layer, extrapolated ---------------------------------------------------
+    S2, V2 = 56, 6
+    T2, K2 = ring_rig(V2, 704, 256)
+    run2, q2, f2 = layer_fn(S2, V2, T2, K2, 704, 256, 64, 176, {"X": 50, "Y": 50, "Z": 2})
+    ta = time.perf_counter()
+    with torch.no_grad():
+        prev = run2(q2, f2[0], None, 1)
+    t_f = time.perf_counter() - ta
+    ta = time.perf_counter()
+    run2(q2, f2[1], prev, 1).square().mean().backward()
+    t_fb = time.perf_counter() - ta
+    per_sample = L * (t_f + t_fb)                         # T = 2: one no-grad frame + one fwd+bwd frame, L layers
+    ratio = (200 ** 2 * (200 // 2) * 200 * D) / float(S2 ** 2 * (S2 // 2) * S2 * D)     # M * N_sca, S=200 over S=56
+    print(f"[bench] cpu_baseline cfg2 geometry S={S2}: layer fwd {t_f:.1f} s, fwd+bwd {t_fb:.1f} s", file=sys.stderr, flush=True)
+    out["cfg2_geometry_s56"] = {
+        "samples_per_s_at_s56": 1.0 / per_sample, "layer_fwd_s": round(t_f, 2), "layer_fwd_bwd_s": round(t_fb, 2),
+        "extrapolated_samples_per_s_at_s200": 1.0 / (per_sample * ratio), "extrapolation": f"EXTRAPOLATED by the M*N ratio "
+        f"({ratio:.0f}x); the materialised formulation cannot run S=200 (16 GB per head, sample and tensor)",
+        "sample": f"6-camera ring, 64x176 features, S={S2} (M={S2 * S2}, N_sca={S2 // 2 * S2 * D} per view), ONE encoder layer "
+                  f"timed forward and forward+backward once each; per sample = L * (fwd + fwd+bwd)"}
+    return out
 
 
 def main():
@@ -189,7 +228,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=4, help="samples per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU (8 = BASELINE config 3, 4 = config 2)")
+    ap.add_argument("--f32-steps", type=int, default=1,
+                    help="also time this many steps in the exact-f32 MFMA mode (rank 0, N=1; 0 = skip)")
     ap.add_argument("--bev", type=int, default=200, help="BEV side (200 = BASELINE config; smaller for debugging)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -267,36 +308,80 @@ def main():
         attn = {k: v for k, v in ktimes.items() if k.startswith("bevr_attn")}
         dom = max(attn, key=lambda k: attn[k]["ms"]) if attn else None
         roof = None
+        # HBM bytes per launch: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command (separate
+        # passes, gfx950 correction applied) by tools/measure_traffic.sh, which writes profiles/r02_traffic.json; only
+        # used when that file was measured at this batch / BEV side / precision
+        traffic_db = {}
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            if tj.get("batch") == B and tj.get("bev") == S and tj.get("precision") == args.precision:
+                traffic_db = tj["kernels"]
         if dom:
             rec = attn[dom]
             avg_ms = rec["ms"] / rec["n"]
             flops = rec["flops"] / rec["n"]
             ach = flops / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            # HBM bytes per launch of that kernel: measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this
-            # very command (separate passes, gfx950 correction applied; see profiles/r01_traffic.json), not live
-            traffic = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-            if S == 200 and B == 4 and args.precision == "bf16" and os.path.exists(tpath):
-                with open(tpath) as fh:
-                    traffic = json.load(fh)["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
             pairs = rec["flops"] / rec["n"] / (2.0 * 32 * {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4}[dom])
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 5), "traffic": traffic, "avg_ms": round(avg_ms, 3),
-                    "launches": rec["n"], "pair_ops_per_s": round(pairs / (avg_ms * 1e-3), 0),
-                    "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 2) for k, v in sorted(ktimes.items())}}
+                    "frac": round(ach / peak, 5), "traffic": traffic_db.get(dom, {}).get("hbm_bytes_per_launch"),
+                    "avg_ms": round(avg_ms, 3), "launches": rec["n"],
+                    "pair_ops_per_s": round(pairs / (avg_ms * 1e-3), 0),
+                    "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 2) for k, v in sorted(ktimes.items())},
+                    "all_attention": {k: {"avg_ms": round(v["ms"] / v["n"], 3),
+                                          "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 5)}
+                                      for k, v in sorted(attn.items())}}
+        # the HBM-bound kernels of the path: bilinear feature sampling, forward and backward scatter.
+        # achieved = algorithmic (compulsory) bytes / launch time: feature map once + one row and one position per key
+        # (forward); + the map's gradient once (backward).  `traffic` = what the PMC counters saw (the backward's
+        # scatter is memory-side float atomics, 4 taps per key)
+        roof_hbm = []
+        for k in ("bevr_sample_fwd", "bevr_sample_bwd"):
+            if k in ktimes and ktimes[k]["ms"] > 0:
+                v = ktimes[k]
+                gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                roof_hbm.append({"bound": "hbm", "kernel": k, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic_db.get(k, {}).get("hbm_bytes_per_launch"),
+                                 "avg_ms": round(v["ms"] / v["n"], 3), "max_ms": round(v["max_ms"], 3), "launches": v["n"],
+                                 "algorithmic_bytes_per_launch": round(v["bytes"] / v["n"])})
         out = {
             "metric": "samples/sec fwd+bwd, 6-cam 256x704 BEV-lift+corr",
             "value": round(total_samples / dt, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearsal else ""),
-            "config": {"workload": f"cfg2+corr: 6-cam 256x704 features (64x64x176), {S}x{S} BEV, C=64 h=2 D=5, L=2 "
-                                   f"encoder layers (TSA+SCA), T=2 (1 no-grad history frame + 1 fwd+bwd), "
-                                   f"contrastive correlation head, AdamW; backbone/render CNN excluded",
+            "config": {"workload": f"cfg{3 if B == 8 else 2}{'' if B == 8 else '+corr'}: 6-cam 256x704 features (64x64x176), "
+                                   f"{S}x{S} BEV, C=64 h=2 D=5, L=2 encoder layers (TSA+SCA), T=2 (1 no-grad history frame "
+                                   f"+ 1 fwd+bwd), correlation head with contrastive + lifted-structure losses, AdamW; "
+                                   f"batch {B} per GPU; backbone/render CNN excluded",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
-            "roofline": roof,
+            "roofline": roof, "roofline_hbm": roof_hbm,
         }
+        if world == 1 and args.f32_steps > 0 and args.precision == "bf16":
+            # the reference's arithmetic is fp32: the same workload in the kernels' exact-f32 MFMA mode, as a secondary
+            # figure (never `value`)
+            del net, opt, model
+            torch.cuda.empty_cache()
+            torch.manual_seed(15213 + rank)
+            m32 = LiftBlock(S, C, heads, D, V, L, img_w, img_h, "f32", dev).to(dev)
+            o32 = torch.optim.AdamW([p for p in m32.parameters() if p.requires_grad], lr=1e-4)
+
+            def step32():
+                o32.zero_grad(set_to_none=True)
+                m32(feats[0], feats[1], map_emb).backward()
+                o32.step()
+            step32()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.f32_steps):
+                step32()
+            torch.cuda.synchronize()
+            d32 = time.perf_counter() - t1
+            out["f32_mode"] = {"value": round(B * args.f32_steps / d32, 4), "unit": "samples/s", "steps": args.f32_steps,
+                               "warmup": 1, "ms_per_step": round(d32 / args.f32_steps * 1e3, 2),
+                               "note": "same workload with exact-f32 MFMA operands (v_mfma_f32_32x32x2_f32), the parity mode"}
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

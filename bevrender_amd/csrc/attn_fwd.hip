@@ -30,7 +30,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 
 template <int PREC> struct Lds {
   static constexpr int EB = Elem<PREC>::bytes;
-  static constexpr int WIN_COLS = 88;                           // table-region columns
+  static constexpr int WIN_COLS = region_cap_fwd(PREC);         // table-region columns
   static constexpr int ENT = PREC == BEVR_PREC_BF16 ? 4 : 8;    // bytes per window entry: (T[y], T[y+1]) as bf16x2 / f32x2
   static constexpr int K_STRIDE = 32 * EB + 16;   // bytes per key row (+16: bank spread)
   static constexpr int V_STRIDE = KT * EB + 16;   // bytes per channel row

@@ -343,10 +343,11 @@ class _Sample(torch.autograd.Function):
         nb, Hi, Wi, Cc = feat.shape
         N = pos.shape[1]
         out = torch.empty(nb, N, Cc, device=feat.device, dtype=torch.float32)
-        # algorithmic HBM bytes: 4 taps read + 1 row written per key, C floats each
+        # algorithmic (compulsory) HBM bytes: the feature map once, a position and an output row per key.  The 4 taps
+        # of a key are NOT 4 HBM reads: neighbouring keys share them through L2 (SURVEY 8d counts the map once too)
         _lib.check(KERNEL_TIMER.run("bevr_sample_fwd", 0.0, _lib.lib().bevr_sample_fwd, _ptr(feat), _ptr(pos),
-                                    _ptr(out), nb, Hi, Wi, Cc, N, _stream(), nbytes=5.0 * nb * N * Cc * 4),
-                   "bevr_sample_fwd")
+                                    _ptr(out), nb, Hi, Wi, Cc, N, _stream(),
+                                    nbytes=4.0 * nb * (Hi * Wi * Cc + N * Cc + 2 * N)), "bevr_sample_fwd")
         ctx.save_for_backward(feat, pos)
         return out
 
@@ -358,10 +359,12 @@ class _Sample(torch.autograd.Function):
         dout = dout.contiguous()
         dfeat = torch.zeros_like(feat)
         dpos = torch.empty_like(pos)
-        # algorithmic HBM bytes: dout row + 4 taps read (position gradient) + 4 taps scattered, C floats each
+        # algorithmic (compulsory) HBM bytes: dout row, position and position gradient per key; the feature map read
+        # once (position gradient) and its gradient written once.  What the scatter really costs is the atomic traffic
+        # (4 taps x N x C floats leave L2 as memory-side atomics): bench.py reports that as `traffic` from the PMC counters
         _lib.check(KERNEL_TIMER.run("bevr_sample_bwd", 0.0, _lib.lib().bevr_sample_bwd, _ptr(feat), _ptr(pos),
                                     _ptr(dout), _ptr(dfeat), _ptr(dpos), nb, Hi, Wi, Cc, N, _stream(),
-                                    nbytes=9.0 * nb * N * Cc * 4), "bevr_sample_bwd")
+                                    nbytes=4.0 * nb * (N * Cc + 2 * Hi * Wi * Cc + 4 * N)), "bevr_sample_bwd")
         return dfeat, dpos
 
 

@@ -113,7 +113,7 @@ def test_bench_launches_its_own_ranks():
     ranks itself.  Rehearsal mode: both ranks on the one GPU over gloo -- the control flow, not a measurement."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(BEVR_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bev", "28", "--batch", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bev", "28", "--batch", "1", "--f32-steps", "0",
                         "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -1,0 +1,40 @@
+"""Sum rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE per kernel (tools/measure_traffic.sh) -> JSON on stdout.
+FETCH_SIZE / WRITE_SIZE are in KB.  Corrections per MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE tallies the
+128-B requests of a wide coalesced read at 64 B, so the read side is doubled; WRITE_SIZE is exact for 16-B streaming
+stores and for float atomics (one dword per lane)."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+root, batch, cmd = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+NAMES = {"attn_fwd_kernel": "bevr_attn_fwd", "attn_bwd_q_kernel": "bevr_attn_bwd_q", "attn_bwd_k_win_kernel": "bevr_attn_bwd_k",
+         "attn_bwd_k_gather_kernel": "bevr_attn_bwd_k", "sample_fwd_kernel": "bevr_sample_fwd", "sample_bwd_kernel": "bevr_sample_bwd"}
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(lambda: collections.defaultdict(int))
+for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    for f in glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            m = re.search(r"(attn_\w+_kernel|sample_\w+_kernel)", r["Kernel_Name"])
+            if not m or m.group(1) not in NAMES:
+                continue
+            k = NAMES[m.group(1)]
+            acc[k][counter] += float(r["Counter_Value"]) * 1024.0
+            if "gather" not in m.group(1):
+                launches[k][counter] += 1
+out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `" + cmd + "`; bytes summed over the "
+                   "launches of the timed AND warm-up step, averaged per launch (bwd_k = window + gather kernels of one call). "
+                   "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B); WRITE_SIZE as "
+                   "read (float atomics and 16-B stores count exactly).",
+       "batch": batch, "bev": 200, "precision": "bf16", "kernels": {}}
+for k in sorted(acc):
+    n = max(launches[k]["FETCH_SIZE"], 1)
+    f = 2.0 * acc[k]["FETCH_SIZE"] / n
+    w = acc[k]["WRITE_SIZE"] / max(launches[k]["WRITE_SIZE"], 1)
+    out["kernels"][k] = {"launches": n, "fetch_bytes_per_launch_corrected": round(f), "write_bytes_per_launch": round(w),
+                         "hbm_bytes_per_launch": round(f + w)}
+print(json.dumps(out, indent=1))

@@ -103,7 +103,11 @@ struct AccCell {
   // whole 64-bit value at once: converting the halves separately rounds the low word of a small NEGATIVE sum
   // (hi = -1, lo = 2^32 - k) to a multiple of 256 units before the halves cancel -- up to 128 units of error per
   // flushed cell, which over the thousands of flushes a table entry receives was 1.3 % of the S = 200 table gradient
-  static __device__ __forceinline__ float to_float(type v) { return (float)(long long)v; }
+  static __device__ __forceinline__ float to_float(type v) {
+    const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+    if (hi == (lo >> 31)) return (float)lo;   // fits 32 bits (nearly always): one conversion instead of the emulated 64-bit one
+    return (float)(long long)v;
+  }
 };
 
 template <int PREC>

@@ -65,9 +65,14 @@ class BEVRender(nn.Module):
                         return_wandb_log=False):
         prev_bev = None
         assert img_tensor.shape[1] == vehicle_pose.shape[1] - 1
-        for i in range(img_tensor.shape[1]):
+        n_hist = img_tensor.shape[1]
+        # the backbones of all history frames as one batch when that is exact: eval mode (BatchNorm on running
+        # statistics), which is how forward() always runs this pass; the recurrence over frames stays
+        feats = self.encoder.history_features(img_tensor) if (n_hist > 1 and not self.training) else None
+        for i in range(n_hist):
             prev_bev = self.encoder(bev_query, img_tensor[:, i], prev_bev, vehicle_pose[:, i:i + 2], vehicle_type_idx,
-                                    wandb_log_dict=wandb_log_dict, return_wandb_log=return_wandb_log)
+                                    wandb_log_dict=wandb_log_dict, return_wandb_log=return_wandb_log,
+                                    img_feat=None if feats is None else feats[i])
         return prev_bev, wandb_log_dict
 
     def init_weights(self):

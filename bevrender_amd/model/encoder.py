@@ -156,11 +156,27 @@ class BEVEncoder(nn.Module):
                             logger=logger, precision=precision)
             for i in range(n_stages)])
 
-    def forward(self, bev_query, img_tensor, prev_bev, vehicle_pose, vehicle_type_idx, wandb_log_dict,
-                return_wandb_log=True):
+    def backbone_features(self, img_tensor):
+        """(B, V, 3, H, W) or (B*V, 3, H, W) camera images -> backbone features (B*V, C, Hf, Wf): the reference's
+        `(b v) c h w` flatten + `img_backbone` (model/encoder.py:98-110)."""
         if img_tensor.dim() == 5:
             img_tensor = img_tensor.flatten(0, 1)                      # views into the batch
-        feat = self.img_backbone(img_tensor)
+        return self.img_backbone(img_tensor)
+
+    def history_features(self, img_tensor):
+        """(B, T', V, 3, H, W) -> list of T' feature tensors (B*V, C, Hf, Wf), all frames through the backbone as ONE
+        batch.  The reference runs the backbone once per history frame inside its recurrent loop
+        (model/bevrender.py:203-219); the history pass runs in eval mode (BatchNorm on running statistics), so the
+        frames are independent and one launch set serves them all."""
+        B, Tn, V = img_tensor.shape[:3]
+        x = img_tensor.permute(1, 0, 2, 3, 4, 5).reshape(Tn * B * V, *img_tensor.shape[3:])   # frame-major
+        feat = self.img_backbone(x)
+        return list(feat.reshape(Tn, B * V, *feat.shape[1:]).unbind(0))
+
+    def forward(self, bev_query, img_tensor, prev_bev, vehicle_pose, vehicle_type_idx, wandb_log_dict,
+                return_wandb_log=True, img_feat=None):
+        """img_feat: backbone features computed ahead (history_features); `img_tensor` is then ignored."""
+        feat = self.backbone_features(img_tensor) if img_feat is None else img_feat
         for stage in self.stages:
             bev_query, wandb_log_dict = stage(bev_query=bev_query, img_tensor=feat, prev_bev=prev_bev,
                                               vehicle_pose=vehicle_pose, vehicle_type_idx=vehicle_type_idx,

@@ -129,6 +129,52 @@ def test_batchnorm_statistics_stay_identical_across_ranks():
     assert np.abs(got[0]).max() > 0
 
 
+def _gather_worker(rank, world, port, w0, x, y, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    parallel.init_distributed("gloo")
+    from bevrender_amd.retrieval import all_gather_embeddings
+    from oracle import bevrender_oracle as O
+    lin = nn.Linear(w0.shape[1], w0.shape[0], bias=False)
+    with torch.no_grad():
+        lin.weight.copy_(w0)
+    net = parallel.wrap_data_parallel(lin)
+    cam = net(parallel.shard_batch(x, rank, world))
+    mp = parallel.shard_batch(y, rank, world)
+    loss = O.contrastive_loss(all_gather_embeddings(cam), all_gather_embeddings(mp))
+    loss.backward()
+    if rank == 0:
+        out_q.put((loss.item(), lin.weight.grad.clone().numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gathered_negatives_give_the_global_batch_gradient():
+    """f3: with the embeddings of every rank gathered (differentiably), each rank's retrieval loss is the loss of the
+    GLOBAL batch, and the data-parallel mean of the per-rank gradients is its gradient."""
+    from oracle import bevrender_oracle as O
+    torch.manual_seed(3)
+    w0 = torch.randn(12, 20) * 0.3
+    x = torch.randn(6, 20)
+    y = x @ w0.t() + 0.5 * torch.randn(6, 12)
+    wr = w0.clone().requires_grad_(True)
+    want = O.contrastive_loss(x @ wr.t(), y)
+    want.backward()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, w0, x, y, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    loss, grad = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert abs(loss - want.item()) < 1e-6
+    np.testing.assert_allclose(grad, wr.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_shard_batch_and_world1_passthrough():
     t = torch.arange(8).reshape(8, 1)
     assert parallel.shard_batch(t, 1, 4).flatten().tolist() == [2, 3]

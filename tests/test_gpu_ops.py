@@ -289,6 +289,32 @@ def test_recall_rank_matches_reference_golden():
         np.testing.assert_allclose(np.array(got), z[f"recall_{tag}"], atol=1e-9)
 
 
+def test_device_recall_matches_reference_golden_and_numpy_at_validation_size():
+    """f3: `retrieval.get_recall` / `RecallAccumulator` (embeddings stay in HBM, Gram as a GEMM, rank count on the
+    device) against the reference's own `get_recall` goldens, and against the oracle's NumPy restatement on a
+    validation-sized set (N = 1 500 rows of E = 4 096) in both the float64 and the float32 form."""
+    from bevrender_amd.retrieval import RecallAccumulator, get_recall
+    z = np.load(os.path.join(GOLDEN, "recall.npz"))
+    for tag in ("a", "b"):
+        cam, mp = torch.tensor(z[f"cam_{tag}"]).to(DEV), torch.tensor(z[f"map_{tag}"]).to(DEV)
+        np.testing.assert_allclose(np.array(get_recall(cam, mp, exact=True)), z[f"recall_{tag}"], atol=1e-9)
+        np.testing.assert_allclose(np.array(get_recall(cam.float(), mp.float(), exact=False)), z[f"recall_{tag}"], atol=1e-9)
+    rng = np.random.default_rng(7)
+    N, E, B = 1500, 4096, 100
+    cam = rng.standard_normal((N, E)).astype(np.float32)
+    mp = (cam + 6.0 * rng.standard_normal((N, E))).astype(np.float32)
+    cam /= np.linalg.norm(cam, axis=1, keepdims=True)
+    mp /= np.linalg.norm(mp, axis=1, keepdims=True)
+    want = O.get_recall(cam.astype(np.float64), mp.astype(np.float64))
+    assert 5 < want[0] < 95
+    acc = RecallAccumulator(N, E, DEV)
+    for i in range(N // B):
+        acc.add(i, torch.tensor(cam[i * B:(i + 1) * B]).to(DEV), torch.tensor(mp[i * B:(i + 1) * B]).to(DEV))
+    np.testing.assert_allclose(np.array(acc.recall(exact=True)), np.array(want), atol=1e-9)
+    # float32 GEMM: a rank can flip only where two distances agree to ~1e-6: allow 3 of the 1 500 columns
+    np.testing.assert_allclose(np.array(acc.recall(exact=False)), np.array(want), atol=100.0 * 3 / N)
+
+
 def test_key_prep_workspace_matches_numpy():
     """bevr_attn_key_prep through the C ABI: per-key (row offset, fraction, clamped column, row relative to the half's
     first row) and the tap box of every 32-key half of a step, against a numpy restatement of the header's contract

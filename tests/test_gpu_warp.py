@@ -121,3 +121,12 @@ def test_full_bevrender_three_frames_runs_the_warp_and_tsa_with_history():
     with torch.no_grad():
         out0, _ = model(img, pose0, vtype, {}, False)
     assert (out1 - out0).abs().max().item() > 1e-5
+    # f4: the history backbones run as one batch; frame by frame (the reference's loop) gives the same history BEV
+    q = model.bev_embedding.weight.t().reshape(1, 64, 28, 28).expand(2, -1, -1, -1)
+    model.eval()
+    with torch.no_grad():
+        batched, _ = model.get_history_bev(q, img[:, :-1], pose1, vtype[0, 0], {}, False)
+        prev = None
+        for i in range(2):
+            prev = model.encoder(q, img[:, i], prev, pose1[:, i:i + 2], vtype[0, 0], wandb_log_dict={}, return_wandb_log=False)
+    np.testing.assert_allclose(batched.cpu().numpy(), prev.cpu().numpy(), rtol=1e-4, atol=1e-4)

@@ -59,15 +59,20 @@ class SCADeformableAttention(nn.Module):
         trunc_normal_(self.rpe_table, std=0.01)
 
     @staticmethod
-    def _offset_head(head, qg):
-        """The reference's offset head (1x1 depthwise C -> C*D, LayerNorm, GELU, 1x1 -> D; :56-77), evaluated
-        channels-last: the depthwise 1x1 is the broadcast multiply it is and the pointwise 1x1 a GEMM (MIOpen
-        runs the fp32 weight gradients of both through reference kernels: 25-61 ms per call at 200x200).
-        Returns (B*g, S, S, D)."""
+    def _offset_head(head, q_nhwc, groups):
+        """The reference's offset head (1x1 depthwise C -> C*D, LayerNorm, GELU, 1x1 -> D; :56-77) on the channels-last
+        query (B, S, S, C) whose `groups` channel groups share the head.  Returns (B*g, S, S, D_out).
+        One fused HIP kernel per call (ops.offset_head, csrc/offset_head.hip: the C*D expansion of a pixel never leaves
+        the wave's registers); shapes the kernel does not cover (more than 64 channels per group, D > 8) run the same
+        arithmetic as stock channels-last ops."""
         dw, norm, act, pw = head[0], head[1], head[2], head[3]
         mult = dw.out_channels // dw.in_channels
+        if q_nhwc.is_cuda and ops.offset_head_supported(dw.in_channels, mult, pw.out_channels):
+            return ops.offset_head(q_nhwc, dw.weight.flatten(), dw.bias, norm.norm.weight, norm.norm.bias,
+                                   pw.weight.flatten(1), groups, norm.norm.eps)
+        B, S1, S2, Cc = q_nhwc.shape
+        qh = q_nhwc.reshape(B, S1, S2, groups, Cc // groups).permute(0, 3, 1, 2, 4).reshape(B * groups, S1, S2, -1, 1)
         # depthwise 1x1 with channel multiplier: out[c * mult + m] = q[c] * w[c * mult + m] + b[c * mult + m], one pass
-        qh = qg.permute(0, 2, 3, 1).unsqueeze(-1)                                 # (B*g, S, S, C, 1) view
         y = torch.addcmul(dw.bias.view(-1, mult), qh, dw.weight.view(-1, mult)).flatten(-2)
         y = F.layer_norm(y, norm.norm.normalized_shape, norm.norm.weight, norm.norm.bias, norm.norm.eps)
         return F.linear(act(y), pw.weight.flatten(1), pw.bias)
@@ -78,11 +83,11 @@ class SCADeformableAttention(nn.Module):
         B, C, S, _ = query.shape
         g, D, V = self.n_groups, self.bev_depth_dim, self.n_views
         Hk, Wk = S // 2, S * D
-        qg = query.reshape(B * g, C // g, S, S)
+        q_nhwc = query.permute(0, 2, 3, 1)            # the LayerNormProxy output underneath: contiguous, no copy
         ref = reference_points[..., (1, 0)]                                  # (B, V, Hk, Wk, 2) -> (y, x)
         outs = []
         for v in range(V):
-            off = self._offset_head(getattr(self, f"conv_offset_m{v}"), qg)  # (B*g, S, S, D) channels-last
+            off = self._offset_head(getattr(self, f"conv_offset_m{v}"), q_nhwc, g)   # (B*g, S, S, D) channels-last
             # "(b g) d (h n) w -> (b g) n h (w d)", n = 2
             off = off.reshape(B * g, Hk, 2, S, D).permute(0, 2, 1, 3, 4).reshape(B * g, 2, Hk, Wk)
             if self.scale_offset_range:

@@ -10,7 +10,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops, resolve_precision
-from .model_utils import LayerNormProxy, depthwise_conv2d, normalized_grid, trunc_normal_
+from .model_utils import (LayerNormProxy, _dw_ok, depthwise_conv2d, depthwise_conv2d_nhwc, normalized_grid,
+                          trunc_normal_)
 
 
 class TSADeformableAttention(nn.Module):
@@ -67,8 +68,18 @@ class TSADeformableAttention(nn.Module):
         g = self.n_groups
         qg = query.reshape(B * g, C // g, H, W)
         co = self.conv_offset
-        y = co[2](co[1](depthwise_conv2d(qg, co[0])))                     # LayerNormProxy output: NHWC underneath
-        off = F.linear(y.permute(0, 2, 3, 1), co[3].weight.flatten(1)).permute(0, 3, 1, 2)   # 1x1 conv as a GEMM
+        if g == 1 and query.is_cuda and _dw_ok(query, co[0]):
+            # stride-1 head on the channels-last query (the LayerNormProxy output underneath): no layout copy
+            z = depthwise_conv2d_nhwc(query.permute(0, 2, 3, 1), co[0]).permute(0, 3, 1, 2)
+        else:
+            z = depthwise_conv2d(qg, co[0])                               # (B*g, Cg, Hk, Wk): the strided k x k depthwise
+        if z.is_cuda and ops.offset_head_supported(z.shape[1], 1, 2):
+            # LayerNorm -> GELU -> 1x1 (Cg -> 2) fused per key-grid pixel (ops.offset_head, csrc/offset_head.hip)
+            off = ops.offset_head(z.permute(0, 2, 3, 1), None, None, co[1].norm.weight, co[1].norm.bias,
+                                  co[3].weight.flatten(1), 1, co[1].norm.eps).permute(0, 3, 1, 2)
+        else:
+            y = co[2](co[1](z))                                           # LayerNormProxy output: NHWC underneath
+            off = F.linear(y.permute(0, 2, 3, 1), co[3].weight.flatten(1)).permute(0, 3, 1, 2)   # 1x1 conv as a GEMM
         Hk, Wk = off.shape[-2:]
         if self.scale_offset_range:
             rng = off.new_tensor([1.0 / (Hk - 1.0), 1.0 / (Wk - 1.0)]).reshape(1, 2, 1, 1)

@@ -447,6 +447,71 @@ def recall_rank(D: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------------
+# fused offset heads (csrc/offset_head.hip)
+# --------------------------------------------------------------------------------------------------
+def offset_head_supported(cg: int, mx: int, dout: int) -> bool:
+    """shapes the fused kernel covers: <= 64 input channels per group; SCA form (Mx == Dout <= 8) or TSA form (1, 2)."""
+    return cg <= 64 and ((mx == dout and 1 <= mx <= 8) or (mx == 1 and dout == 2))
+
+
+class _OffsetHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, b0, gamma, beta, W3, groups, eps):
+        _require_gpu(x, gamma, beta, W3)
+        x = x.float().contiguous()
+        B, H, W, Cc = x.shape
+        g = groups
+        cg = Cc // g
+        K = gamma.numel()
+        mx, dout = K // cg, W3.shape[0]
+        prm = [None if t is None else t.detach().float().contiguous() for t in (w0, b0, gamma, beta, W3)]
+        P = B * H * W
+        out = torch.empty(g, B, H, W, dout, device=x.device, dtype=torch.float32)
+        L = _lib.lib()
+        for gi in range(g):
+            xp = C.c_void_p(x.data_ptr() + gi * cg * 4)
+            _lib.check(L.bevr_offset_head_fwd(xp, _ptr(prm[0]), _ptr(prm[1]), _ptr(prm[2]), _ptr(prm[3]), _ptr(prm[4]),
+                                              _ptr(out[gi]), P, cg, Cc, mx, dout, float(eps), _stream()),
+                       "bevr_offset_head_fwd")
+        ctx.save_for_backward(x, *[t for t in prm if t is not None])
+        ctx.meta = (g, cg, mx, dout, float(eps), w0 is not None, b0 is not None)
+        return out.permute(1, 0, 2, 3, 4).reshape(B * g, H, W, dout)
+
+    @staticmethod
+    def backward(ctx, dout_):
+        g, cg, mx, dout, eps, has_w0, has_b0 = ctx.meta
+        saved = list(ctx.saved_tensors)
+        x = saved.pop(0)
+        w0 = saved.pop(0) if has_w0 else None
+        b0 = saved.pop(0) if has_b0 else None
+        gamma, beta, W3 = saved
+        B, H, W, Cc = x.shape
+        P = B * H * W
+        do = dout_.float().reshape(B, g, H, W, dout).permute(1, 0, 2, 3, 4).contiguous()
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        dw0 = torch.zeros_like(w0) if has_w0 else None
+        db0 = torch.zeros_like(b0) if has_b0 else None
+        dga, dbe, dW3 = torch.zeros_like(gamma), torch.zeros_like(beta), torch.zeros_like(W3)
+        L = _lib.lib()
+        for gi in range(g):
+            xp = C.c_void_p(x.data_ptr() + gi * cg * 4)
+            dxp = None if dx is None else C.c_void_p(dx.data_ptr() + gi * cg * 4)
+            _lib.check(L.bevr_offset_head_bwd(xp, _ptr(w0), _ptr(b0), _ptr(gamma), _ptr(beta), _ptr(W3), _ptr(do[gi]), dxp,
+                                              _ptr(dw0), _ptr(db0), _ptr(dga), _ptr(dbe), _ptr(dW3), P, cg, Cc, mx, dout,
+                                              eps, _stream()), "bevr_offset_head_bwd")
+        return dx, dw0, db0, dga, dbe, dW3, None, None
+
+
+def offset_head(x: torch.Tensor, w0, b0, gamma: torch.Tensor, beta: torch.Tensor, W3: torch.Tensor, groups: int = 1,
+                eps: float = 1e-5) -> torch.Tensor:
+    """Fused offset head on a channels-last map.  x (B, H, W, C); the C channels are `groups` groups that share the
+    head; w0, b0 (Cg*Mx,) depthwise 1x1 weights with channel multiplier Mx, or None (no expansion: z = x);
+    gamma, beta (Cg*Mx,) LayerNorm; W3 (Dout, Cg*Mx) pointwise, no bias.  Returns (B*groups, H, W, Dout), rows in
+    the reference's "(b g)" order.  Replaces model/SCA_deform_attn.py:56-77 / model/TSA_deform_attn.py:54-68 (tail)."""
+    return _OffsetHead.apply(x, w0, b0, gamma, beta, W3, groups, eps)
+
+
+# --------------------------------------------------------------------------------------------------
 # ego-motion warp of the history BEV (csrc/warp.hip)
 # --------------------------------------------------------------------------------------------------
 class _AffineWarp(torch.autograd.Function):

@@ -20,6 +20,7 @@
  *   bevr_attn_fwd/bwd_*     model/SCA_deform_attn.py:331-413, model/TSA_deform_attn.py:245-333
  *                           (QK^T*scale + bilinear RPE bias + softmax + PV, never materialised)
  *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
+ *   bevr_offset_head_fwd/bwd  model/SCA_deform_attn.py:56-77, model/TSA_deform_attn.py:54-68 (offset heads, fused)
  *   bevr_affine_warp_fwd/bwd  model/encoder.py:413-466 (project_history_bev_feat: torchvision F.affine, twice)
  *   bevr_corr_fwd/bwd       train.py:554 (2 - 2 cam map^T) and the pairwise distance inside
  *                           loss/contrastive_loss.py:10-19 / loss/lift_loss.py:13-22
@@ -193,6 +194,25 @@ int bevr_dwconv_fwd(const float* x, const float* w, const float* bias, float* y,
                     int B, int H, int W, int C, int k, int nhwc, int flip, void* stream);
 int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
                       int B, int H, int W, int C, int k, int nhwc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Offset heads of the deformable attention blocks, fused per BEV pixel (model/SCA_deform_attn.py:56-77 conv_offset_m{v};
+ * the LayerNorm -> GELU -> 1x1 tail of model/TSA_deform_attn.py:54-68):
+ *   z[c*Mx + m] = x[c] * w0[c*Mx + m] + b0[c*Mx + m]   (depthwise 1x1, channel multiplier Mx; w0 == NULL: z = x, Mx = 1)
+ *   out[d] = sum_k W3[d][k] * GELU_erf( LayerNorm_{Cg*Mx}(z)[k] * gamma[k] + beta[k] )
+ *   x   [P pixels][xstride] float, the head's Cg <= 64 input channels first (a channel group of a channels-last tensor:
+ *       pass the pointer to the group's first channel and xstride = the tensor's channel count)
+ *   w0, b0, gamma, beta [Cg*Mx], W3 [Dout][Cg*Mx], out [P][Dout] float.  (Mx, Dout) = (1, 2) or Mx == Dout <= 8.
+ * backward: dx [P][xstride] (may be NULL) and every parameter gradient are ACCUMULATED (caller zeroes them);
+ *   dw0 / db0 may be NULL (TSA form).
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_offset_head_fwd(const float* x, const float* w0, const float* b0, const float* gamma, const float* beta,
+                         const float* W3, float* out, long long P, int Cg, int xstride, int Mx, int Dout, float eps,
+                         void* stream);
+int bevr_offset_head_bwd(const float* x, const float* w0, const float* b0, const float* gamma, const float* beta,
+                         const float* W3, const float* dout, float* dx, float* dw0, float* db0, float* dgamma,
+                         float* dbeta, float* dW3, long long P, int Cg, int xstride, int Mx, int Dout, float eps,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ego-motion warp of the history BEV (model/encoder.py:413-466): one torchvision-style affine resampling,

@@ -372,6 +372,42 @@ def test_key_prep_workspace_matches_numpy():
             np.testing.assert_allclose(kw[p, sl, 2].view(np.float32)[lv], bn[p, sl][lv].astype(np.float32), rtol=1e-6)
 
 
+@pytest.mark.parametrize("cfg", [(2, 9, 7, 64, 1, 5, 5), (1, 6, 6, 16, 2, 3, 3), (2, 5, 8, 32, 1, 1, 2), (1, 4, 4, 48, 3, 1, 2),
+                                 (3, 20, 20, 64, 1, 1, 2)])
+def test_fused_offset_head_matches_the_stock_op_chain(cfg):
+    """bevr_offset_head_fwd/bwd (depthwise 1x1 with multiplier -> LayerNorm -> GELU -> 1x1, fused per pixel) against
+    the reference's op chain in float64: SCA form (Mx = Dout = D), TSA form (no expansion, 2 outputs), channel groups
+    that share the head, fewer than 64 channels per group (masked lanes)."""
+    B, H, W, Cc, g, mx, dout = cfg
+    cg = Cc // g
+    K = cg * mx
+    gen = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, H, W, Cc, generator=gen)
+    w0 = (torch.randn(K, generator=gen) * 0.7) if (mx > 1 or dout == mx) else None
+    b0 = torch.randn(K, generator=gen) * 0.3 if w0 is not None else None
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=gen), 0.1 * torch.randn(K, generator=gen)
+    W3 = torch.randn(dout, K, generator=gen) / K ** 0.5
+    cot = torch.randn(B * g, H, W, dout, generator=gen)
+
+    def ref(x, w0, b0, gamma, beta, W3):
+        xg = x.reshape(B, H, W, g, cg).permute(0, 3, 1, 2, 4).reshape(B * g, H, W, cg)
+        z = xg if w0 is None else (xg.unsqueeze(-1) * w0.view(cg, mx) + b0.view(cg, mx)).flatten(-2)
+        y = F.gelu(F.layer_norm(z, (K,), gamma, beta, 1e-5))
+        return y @ W3.t()
+    pc = [None if t is None else t.clone().double().requires_grad_(True) for t in (x, w0, b0, gamma, beta, W3)]
+    want = ref(*pc)
+    want.backward(cot.double())
+    pg = [None if t is None else t.clone().to(DEV).requires_grad_(True) for t in (x, w0, b0, gamma, beta, W3)]
+    got = ops.offset_head(pg[0], pg[1], pg[2], pg[3], pg[4], pg[5], groups=g)
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-5)
+    for name, a, b in zip(("x", "w0", "b0", "gamma", "beta", "W3"), pg, pc):
+        if a is None:
+            continue
+        assert rel_err(a.grad.cpu().double(), b.grad) < 2e-5, name
+
+
 @pytest.mark.parametrize("nhwc", [False, True])
 @pytest.mark.parametrize("shape", [(2, 8, 9, 7, 3), (1, 64, 40, 40, 3), (2, 5, 6, 11, 5), (1, 3, 4, 4, 1)])
 def test_depthwise_conv_matches_torch(shape, nhwc):

@@ -125,40 +125,54 @@ __device__ __forceinline__ void key_split(float a, float b, const bevr_attn_desc
   fy = a - af;
 }
 
-template <int PREC> struct LdsK {
+// NT = 32-query tiles staged (and processed) per barrier
+template <int PREC, int NT = 1> struct LdsK {
   static constexpr int EB = Elem<PREC>::bytes;
-  static constexpr int STRIDE = 32 * EB + 16;  // every tile is 32 rows x 32 elements
-  static constexpr int TILE = 32 * STRIDE;
-  static constexpr int BUF = 4 * TILE + 2 * QT * 4;  // Q, dO, Qt, dOt, lse, delta
+  static constexpr int QTILE = NT * 32;
+  static constexpr int STRIDE = 32 * EB + 16;            // row-layout tiles (Q, dO): bytes per query row
+  static constexpr int TSTRIDE = QTILE * EB + 16;        // transposed tiles (Qt, dOt): bytes per channel row
+  static constexpr int TILE_Q = QTILE * STRIDE;
+  static constexpr int TILE_T = 32 * TSTRIDE;
+  static constexpr int TILE = TILE_Q;                     // NT = 1: all four tiles are 32 rows x 32 elements
+  static constexpr int BUF = 2 * TILE_Q + 2 * TILE_T + 2 * QTILE * 4;  // Q, dO, Qt, dOt, lse, delta
   static constexpr int WCAP = PREC == BEVR_PREC_BF16 ? 30720 : 26624;   // ring capacity, f32 entries (one workgroup per CU)
 };
 
 // ---- query-tile staging shared by both kernels ----------------------------------------------------------
-template <int PREC, int THREADS> struct QStage {
-  typedef LdsK<PREC> L;
+template <int PREC, int THREADS, int NT = 1> struct QStage {
+  typedef LdsK<PREC, NT> L;
   static constexpr int EB = L::EB;
-  static constexpr int CHR = 32 * EB / 16;            // 16-B chunks per 32-element row
-  static constexpr int CH_ARR = 32 * CHR;             // chunks per tile (128 / 256)
+  static constexpr int QTILE = L::QTILE;
+  static constexpr int CHR = 32 * EB / 16;            // 16-B chunks per 32-element query row (Q, dO)
+  static constexpr int CHT = QTILE * EB / 16;         // 16-B chunks per channel row of QTILE queries (Qt, dOt)
+  static constexpr int CH_ARR = QTILE * CHR;          // chunks per array: QTILE * CHR = 32 * CHT
   static constexpr int NCH = (4 * CH_ARR + THREADS - 1) / THREADS;    // chunks per thread (the last slot may be partial)
   u32x4 st[NCH];
   float st_c;
   const char* base[NCH];    // array base pointer (uniform per chunk slot: the array index is wave-uniform)
-  unsigned off[NCH];        // per-thread byte offset inside the array for tile 0
+  unsigned off[NCH];        // per-thread byte offset inside the array for query 0
   int mul[NCH];             // bytes per query index step
   int dst[NCH];
-  const float* cbase;       // wave 0: LSE row constants, wave 1: delta (lanes < 32 each)
+  const float* cbase;       // wave 0: LSE row constants, wave 1: delta
 
   __device__ __forceinline__ void init(int tid, const char* Qh, const char* dOh, const char* Qth, const char* dOth,
                                        const float* LSEh, const float* dlth, int Mp) {
+    static_assert(CH_ARR % 64 == 0, "a chunk slot's array must be wave-uniform");
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int cid = tid + c * THREADS;
       const int arr = __builtin_amdgcn_readfirstlane(cid / CH_ARR), a = cid % CH_ARR;
-      const int row = a / CHR, cc = a % CHR;
       base[c] = arr == 0 ? Qh : arr == 1 ? dOh : arr == 2 ? Qth : dOth;   // arr >= 4: idle slot (dst < 0)
-      if (arr < 2 || arr >= 4) { off[c] = (unsigned)a * 16; mul[c] = 32 * EB; }
-      else { off[c] = (unsigned)(((size_t)row * Mp) * EB + cc * 16); mul[c] = EB; }
-      dst[c] = cid < 4 * CH_ARR ? arr * L::TILE + row * L::STRIDE + cc * 16 : -1;
+      if (arr < 2 || arr >= 4) {
+        const int row = a / CHR, cc = a % CHR;
+        off[c] = (unsigned)a * 16; mul[c] = 32 * EB;
+        dst[c] = arr * L::TILE_Q + row * L::STRIDE + cc * 16;
+      } else {
+        const int row = a / CHT, cc = a % CHT;
+        off[c] = (unsigned)(((size_t)row * Mp) * EB + cc * 16); mul[c] = EB;
+        dst[c] = 2 * L::TILE_Q + (arr - 2) * L::TILE_T + row * L::TSTRIDE + cc * 16;
+      }
+      if (cid >= 4 * CH_ARR) dst[c] = -1;
     }
     st_c = 0.f;
     cbase = (tid >> 6) == 0 ? LSEh : dlth;
@@ -167,13 +181,14 @@ template <int PREC, int THREADS> struct QStage {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
       if (dst[c] >= 0) st[c] = *reinterpret_cast<const u32x4*>(base[c] + mq0 * mul[c] + off[c]);
-    if (tid < 128 && (tid & 63) < QT) st_c = -cbase[mq0 + (tid & 63)];   // negated: they seed the accumulators
+    if (tid < 128 && (tid & 63) < QTILE) st_c = -cbase[mq0 + (tid & 63)];   // negated: they seed the accumulators
   }
   __device__ __forceinline__ void store(int tid, char* buf) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
       if (dst[c] >= 0) *reinterpret_cast<u32x4*>(buf + dst[c]) = st[c];
-    if (tid < 128 && (tid & 63) < QT) *reinterpret_cast<float*>(buf + 4 * L::TILE + ((tid >> 6) * QT + (tid & 63)) * 4) = st_c;
+    if (tid < 128 && (tid & 63) < QTILE)
+      *reinterpret_cast<float*>(buf + 2 * L::TILE_Q + 2 * L::TILE_T + ((tid >> 6) * QTILE + (tid & 63)) * 4) = st_c;
   }
 };
 
@@ -190,8 +205,15 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
     const char* __restrict__ table_pair, const char* __restrict__ dO, const char* __restrict__ dOt,
     const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV,
     float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
-  typedef LdsK<PREC> L;
+  // NT 32-query tiles are staged and processed per barrier.  With one tile per barrier the three waves of a SIMD
+  // ran in lockstep -- MFMAs together, then the VALU-bound bias / exp / gradient loop together, then the barrier --
+  // and each pipe idled while the other worked; with two, the waves drift apart inside an iteration and one wave's
+  // MFMAs overlap another's VALU phase, and there are half as many barriers.  (f32 mode keeps one: its tiles are
+  // twice the bytes and the LDS ring leaves no room.)
+  constexpr int NT = PREC == BEVR_PREC_BF16 ? 2 : 1;
+  typedef LdsK<PREC, NT> L;
   constexpr int EB = L::EB;
+  static_assert(2 * L::BUF + L::WCAP * 4 + 256 <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
   __shared__ __attribute__((aligned(16))) float win[L::WCAP];
   __shared__ __attribute__((aligned(16))) KBox red[TW / 64];
@@ -287,12 +309,17 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
     da[w] = 0.f; db[w] = 0.f; fx[w] = 0.f; base0[w] = 0; base1[w] = 0;
   }
 
-  QStage<PREC, TW> qs;
+  QStage<PREC, TW, NT> qs;
   qs.init(tid, Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB, dO + ((size_t)ph * Mp) * 32 * EB,
           Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB, dOt + ((size_t)ph * 32) * Mp * EB,
           LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp);
-  const int n_it = d.S * n_rb;
-  qs.load(tid, 0);
+  // tile t = (BEV column j = t / n_rb, row block rb = t % n_rb) is the 32 packed queries [32 t, 32 t + 32): consecutive
+  // tiles are contiguous in memory.  Iteration `it` stages the NT tiles from first_tile(it); when the tile count is odd
+  // the last iteration re-stages the previous tile in front of the last one (never reads past the array) and skips it.
+  const int n_tile = d.S * n_rb;
+  const int n_it = (n_tile + NT - 1) / NT;
+  auto first_tile = [&](int it) { return NT == 1 ? it : max(0, min(NT * it, n_tile - NT)); };
+  qs.load(tid, (size_t)first_tile(0) * 32);
   qs.store(tid, smem);
 
   // ring state (uniform): table columns [wlo, whi] are resident; column X lives in slot (X - xbase) % ncw
@@ -321,11 +348,15 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
     PROF_TD(t0, 0.f);
     const int buf = it & 1;
     const char* base = smem + buf * L::BUF;
-    const int j = it / n_rb, rb = it - j * n_rb;
-    if (it + 1 < n_it) {
-      const int jn = (it + 1) / n_rb, rbn = (it + 1) - jn * n_rb;
-      qs.load(tid, (size_t)jn * d.Sp + rbn * 32);
-    }
+    const int t_first = first_tile(it);
+    if (it + 1 < n_it) qs.load(tid, (size_t)first_tile(it + 1) * 32);
+    int pf_first = 0, pf_units = 0;
+    float pf_v[PF];
+#pragma unroll
+    for (int sub = 0; sub < NT; ++sub) {
+    const int t = t_first + sub;
+    if (t < NT * it) continue;   // the re-staged tile of an odd tail: already processed (uniform)
+    const int j = t / n_rb, rb = t - j * n_rb;
     if (rb == 0) {
       // ---- new BEV column: make its table columns resident and refresh the lanes' tap bases -----------
       const float jr = (float)j * rx;
@@ -357,10 +388,10 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
       }
     }
     // prefetch of the next BEV column's new table columns: loads now, LDS stores before this iteration's barrier
-    // (their slots are outside the current column's range: make_slab reserved the room)
-    int pf_first = 0, pf_units = 0;
-    float pf_v[PF];
-    if (rb == n_rb - 1 && j + 1 < d.S) {
+    // (their slots are outside the current column's range: make_slab reserved the room).  Only when the column's last
+    // tile is also the iteration's last: otherwise the next column starts before that barrier and fetches its
+    // columns itself (the `whi < xhi` path above, with its own barrier).
+    if (sub == NT - 1 && rb == n_rb - 1 && j + 1 < d.S) {
       const float jr = (float)(j + 1) * rx;
       const int xhi = (int)floorf(jr + box.bmax) + 1;
       const int xfirst = max(whi + 1, (int)floorf(jr + box.bmin));
@@ -386,12 +417,12 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
 #pragma unroll
     for (int w = 0; w < KWW; ++w) {
       if (!wave_live[w]) continue;
-      const f32x4* rc = reinterpret_cast<const f32x4*>(base + 4 * L::TILE);
+      const f32x4* rc = reinterpret_cast<const f32x4*>(base + 2 * L::TILE_Q + 2 * L::TILE_T) + sub * 8;
       f32x16 s, dp;
       // one operand fragment alive at a time (the register budget is 128): S first, then dP
       {
         Frag<PREC> qf;
-        qf.load(base + lq * L::STRIDE, hi);
+        qf.load(base + (sub * 32 + lq) * L::STRIDE, hi);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {   // rows 8 g4 + 4 hi + 0..3
           const f32x4 l4 = rc[2 * g4 + hi];
@@ -402,10 +433,10 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
       }
       {
         Frag<PREC> dof;
-        dof.load(base + L::TILE + lq * L::STRIDE, hi);
+        dof.load(base + L::TILE_Q + (sub * 32 + lq) * L::STRIDE, hi);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 d4 = rc[8 + 2 * g4 + hi];
+          const f32x4 d4 = rc[NT * 8 + 2 * g4 + hi];
 #pragma unroll
           for (int k = 0; k < 4; ++k) dp[4 * g4 + k] = d4[k];
         }
@@ -457,17 +488,19 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
       PROF_ADD(2, t3 - t2);
       {
         Frag<PREC> dotf;
-        load_perm(dotf, base + 3 * L::TILE + lq * L::STRIDE, hi);
+        load_perm(dotf, base + 2 * L::TILE_Q + L::TILE_T + lq * L::TSTRIDE + sub * 32 * EB, hi);
         dv[w] = mma_acc_b(dotf, s, dv[w]);
       }
       {
         Frag<PREC> qtf;
-        load_perm(qtf, base + 2 * L::TILE + lq * L::STRIDE, hi);
+        load_perm(qtf, base + 2 * L::TILE_Q + lq * L::TSTRIDE + sub * 32 * EB, hi);
         dk[w] = mma_acc_b(qtf, dp, dk[w]);
       }
       PROF_TD(t4, dk[w][0] + dv[w][0]);
       PROF_ADD(3, t4 - t3);
     }
+
+    }   // sub-tiles
 
     PROF_TD(t5, 0.f);
     if (pf_units > 0) {

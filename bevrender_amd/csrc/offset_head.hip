@@ -155,25 +155,35 @@ __global__ __launch_bounds__(OH_THREADS) void offset_head_bwd_kernel(
     }
     if (on && dx) atomicAdd(dx + pix * xstride + lane, dxc);
   }
-  // parameter gradients: one atomic per parameter and wave (the head has a few thousand parameters)
+  // parameter gradients: summed over the workgroup's waves in LDS, then ONE global atomic per parameter and workgroup
+  // (one per wave put 8 192 waves on the same 2 880 addresses: 1.4 ms per launch of same-address contention)
+  __shared__ float pg[(4 + OH_MAXD) * 64 * OH_MAXM];
+  const int K = Cg * Mx;
+  for (int i = threadIdx.x; i < (4 + Dout) * K; i += OH_THREADS) pg[i] = 0.f;
+  __syncthreads();
   if (on) {
-    const int K = Cg * Mx;
 #pragma unroll
     for (int m = 0; m < Mx; ++m) {
       const int k = lane * Mx + m;
-      if (dw0) atomicAdd(dw0 + k, gw0[m]);
-      if (db0) atomicAdd(db0 + k, gb0[m]);
-      atomicAdd(dgamma + k, gga[m]);
-      atomicAdd(dbeta + k, gbe[m]);
+      atomicAdd(pg + k, gw0[m]);
+      atomicAdd(pg + K + k, gb0[m]);
+      atomicAdd(pg + 2 * K + k, gga[m]);
+      atomicAdd(pg + 3 * K + k, gbe[m]);
 #pragma unroll
-      for (int d = 0; d < Dout; ++d) atomicAdd(dW3 + (size_t)d * K + k, gw3[d][m]);
+      for (int d = 0; d < Dout; ++d) atomicAdd(pg + (4 + d) * K + k, gw3[d][m]);
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (4 + Dout) * K; i += OH_THREADS) {
+    const int which = i / K, k = i - which * K;
+    float* dst = which == 0 ? dw0 : which == 1 ? db0 : which == 2 ? dgamma : which == 3 ? dbeta : dW3 + (size_t)(which - 4) * K;
+    if (dst) atomicAdd(dst + k, pg[i]);
   }
 }
 
 int oh_grid(long long P) {
   long long g = (P + (OH_THREADS / 64) * 16 - 1) / ((OH_THREADS / 64) * 16);   // >= 16 pixels per wave: amortises the parameter load
-  if (g > 256 * 8) g = 256 * 8;
+  if (g > 256 * 4) g = 256 * 4;   // 4 workgroups per CU: enough waves to hide the loads, few enough parameter-gradient atomics
   if (g < 1) g = 1;
   return (int)g;
 }

@@ -184,3 +184,62 @@ def test_encoder_layer_s56_matches_reference():
         g = ins[name[len("grad_in."):]].grad if name.startswith("grad_in.") else p[name[len("grad_param."):]].grad
         assert g is not None, name
         check_sampled(z, name, g, rtol=1e-3, atol_frac=1e-4, floor_frac=2e-6)
+
+
+def test_streaming_and_row_subset_forms_equal_the_materialised_core():
+    """oracle.attention_core_streaming (tiled keys, online softmax, explicit 4-tap lookup at ty = i + a, tx = j rx + b:
+    the algorithmic twin of csrc/attn_fwd.hip) and attention_core(rows=...) against the materialised formulation that
+    the goldens pin -- float64, keys on / outside the border, g = 1 and g = 2."""
+    torch.manual_seed(0)
+    for (B, h, g, c, S, D, N) in [(2, 2, 1, 8, 6, 3, 50), (1, 4, 2, 4, 8, 2, 70)]:
+        M = S * S
+        q = torch.randn(B * h, c, M, dtype=torch.float64)
+        k = torch.randn(B * h, c, N, dtype=torch.float64)
+        v = torch.randn(B * h, c, N, dtype=torch.float64)
+        pos = (torch.rand(B * g, N, 2, dtype=torch.float64) * 2 - 1) * 1.3
+        pos[0, 0] = torch.tensor([-1.0, -1.0])
+        pos[0, 1] = torch.tensor([1.0, 1.0])
+        pos[0, 2] = torch.tensor([-3.0, 3.0])
+        tab = torch.randn(h, 2 * S - 1, 2 * S * D - 1, dtype=torch.float64)
+        full = O.attention_core(q, k, v, pos, tab, S, S, g, c ** -0.5)
+        stream = O.attention_core_streaming(q, k, v, pos, tab, S, S, g, c ** -0.5, tile=16)
+        np.testing.assert_allclose(stream.numpy(), full.numpy(), rtol=0, atol=1e-12)
+        rows = torch.tensor([0, 5, M - 1, 7])
+        sub = O.attention_core(q, k, v, pos, tab, S, S, g, c ** -0.5, rows=rows)
+        np.testing.assert_array_equal(sub.numpy(), full[:, :, rows].numpy())
+
+
+def test_ego_motion_warp_restatement_properties():
+    """oracle.tv_affine / project_history_bev_feat (PARITY UNPINNED: torchvision absent): zero pose is the identity,
+    an integer translation is a shift with zero fill, a half-pixel shift attenuates the border twice (value x mask),
+    and the two chained resamplings of model/encoder.py:436-453 compose as written."""
+    torch.manual_seed(1)
+    img = torch.randn(3, 6, 7)
+    np.testing.assert_allclose(O.tv_affine(img, 0.0, (0, 0)).numpy(), img.numpy(), atol=2e-6)
+    shifted = torch.zeros_like(img)
+    shifted[:, :5, 2:] = img[:, 1:, :5]
+    np.testing.assert_allclose(O.tv_affine(img, 0.0, (2, -1)).numpy(), shifted.numpy(), atol=2e-6)
+    half = O.tv_affine(torch.ones(1, 4, 4), 0.0, (0.5, 0.0))
+    np.testing.assert_allclose(half[0, :, 0].numpy(), 0.25, atol=1e-6)
+    np.testing.assert_allclose(half[0, :, 1:].numpy(), 1.0, atol=1e-6)
+    bev = torch.randn(2, 3, 8, 8)
+    pose = torch.tensor([[[1.0, 2.0, 0.3], [0.5, -1.0, -0.2]], [[0.0, 0.0, 0.0], [0.0, 0.0, 0.0]]])
+    out = O.project_history_bev_feat(bev, pose)
+    want0 = O.tv_affine(O.tv_affine(bev[0], np.degrees(0.3), (0.5, 3.0)), np.degrees(0.2), (0.0, 0.0))
+    np.testing.assert_allclose(out[0].numpy(), want0.numpy(), atol=1e-6)
+    np.testing.assert_allclose(out[1].numpy(), bev[1].numpy(), atol=4e-6)
+
+
+def test_triplet_loss_restatement_properties():
+    """oracle.triplet_margin_loss (PARITY UNPINNED): without semi-hard triplets only the embedding regulariser remains;
+    with them the loss exceeds it; gradients flow."""
+    torch.manual_seed(2)
+    cam = torch.randn(6, 32, dtype=torch.float64, requires_grad=True)
+    far = O.triplet_margin_loss(cam, cam.detach() + 1e-3 * torch.randn(6, 32, dtype=torch.float64))
+    reg = torch.cat((cam, cam)).norm(dim=1).mean()
+    assert abs(far.item() - reg.item()) < 1e-2                    # positives far closer than any negative: nothing mined
+    mp = (cam.detach() + 3.0 * torch.randn(6, 32, dtype=torch.float64)).requires_grad_(True)
+    loss = O.triplet_margin_loss(cam, mp)
+    loss.backward()
+    assert loss.item() >= torch.cat((cam, mp)).norm(dim=1).mean().item() - 1e-12
+    assert cam.grad.abs().sum() > 0

@@ -16,6 +16,16 @@ TSA = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "tsa_*.
 SCA = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "sca_*.npz")))
 
 
+LIM_BF16 = 3e-2   # gradients, bf16 operand mode, relative to the tensor's largest entry (observed worst on MI355X: 1.2e-2;
+                  # f32 mode observed 8.2e-6 against its 1e-3)
+WORST = {}
+
+
+def teardown_module(module):
+    print("\n[modules] worst gradient error / max |want| (gradients above the reference's noise floor):",
+          {("f32" if k == _lib.PREC_F32 else "bf16"): f"{v:.3e}" for k, v in WORST.items()})
+
+
 def load(name):
     z = np.load(os.path.join(GOLDEN, name))
     return {k: z[k] for k in z.files}
@@ -29,11 +39,11 @@ def load_params(mod, z):
 
 def check(mod, z, out, inputs, prec):
     f32 = prec == _lib.PREC_F32
-    np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=3e-4 if f32 else 5e-2,
-                               atol=3e-5 if f32 else 3e-2)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=3e-4 if f32 else 3e-2,
+                               atol=3e-5 if f32 else 2e-2)
     out.backward(torch.tensor(z["cot"]).to(DEV))
     torch.cuda.synchronize()
-    lim = 1e-3 if f32 else 8e-2
+    lim = 2e-4 if f32 else LIM_BF16
     # absolute floor: some reference gradients are pure rounding noise (proj_k.bias shifts every logit of a
     # query equally, so its true gradient is 0)
     floor = (2e-5 if f32 else 2e-3) * max(np.abs(v).max() for k, v in z.items() if k.startswith("grad_"))
@@ -47,6 +57,8 @@ def check(mod, z, out, inputs, prec):
         else:
             continue
         err = np.abs(g - v).max() / (np.abs(v).max() + 1e-12)
+        if np.abs(v).max() > 20 * floor:   # gradients that are not rounding noise in the reference itself
+            WORST[prec] = max(WORST.get(prec, 0.0), err)
         assert np.abs(g - v).max() <= lim * np.abs(v).max() + floor, f"{k}: rel err {err:.3e}"
 
 

@@ -16,7 +16,7 @@ DEV = "cuda"
 
 # tolerances: F32 = exact-f32 MFMA, differences are summation order + the algebraic bias reformulation;
 # BF16 = bf16 operands (Q, K, V, P, dO, dS), f32 accumulation.
-TOL = {_lib.PREC_F32: dict(rtol=2e-4, atol=2e-5), _lib.PREC_BF16: dict(rtol=4e-2, atol=2e-2)}
+TOL = {_lib.PREC_F32: dict(rtol=2e-4, atol=2e-5), _lib.PREC_BF16: dict(rtol=3e-2, atol=1.5e-2)}
 
 
 def rel_err(got, want):
@@ -78,7 +78,7 @@ def test_attention_core_forward_backward(cfg, prec):
     got.backward(cot.to(DEV))
     torch.cuda.synchronize()
     names = ["query", "k", "v", "pos", "table"]
-    lim = 5e-4 if prec == _lib.PREC_F32 else 5e-2
+    lim = 5e-4 if prec == _lib.PREC_F32 else 3e-2
     for n, a, b in zip(names, ins_gpu, ins_cpu):
         e = rel_err(a.grad.cpu(), b.grad)
         assert e < lim, f"grad {n}: rel err {e:.3e}"

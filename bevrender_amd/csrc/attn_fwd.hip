@@ -21,6 +21,24 @@
 // through that XCD's L2.
 #include "attn_tile.h"
 
+#ifdef BEVR_PROF
+__device__ unsigned long long bevr_prof_fwd[16];
+extern "C" int bevr_debug_prof_fwd(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(bevr_prof_fwd), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bevr_prof_fwd), 16 * 8);
+}
+__device__ __forceinline__ unsigned long long prof_now_f(float dep) {
+  unsigned long long t;
+  asm volatile("s_nop 0\n s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  return t;
+}
+#define PROF_TD(var, dep) const unsigned long long var = prof_now_f(dep)
+#define PROF_ADD(i, v) pacc[i] += (v)
+#else
+#define PROF_TD(var, dep)
+#define PROF_ADD(i, v)
+#endif
+
 namespace {
 
 constexpr float RESCALE_THR = 8.0f;  // log2 units: lazy running-max update (P <= 2^8)
@@ -170,7 +188,11 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   // boxes of the two 32-key halves of a step: uniform (scalar loads), fetched one step ahead
   StepBox sb_cur[2] = {kbox[0], kbox[1]};
   StepBox sb_nxt[2] = {kbox[2 * min(1, n_step - 1)], kbox[2 * min(1, n_step - 1) + 1]};
+#ifdef BEVR_PROF
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int step = 0; step < n_step; ++step) {
+    PROF_TD(t0, 0.f);
     const int buf = step & 1;
     const char* base = smem + buf * L::BUF;
     if (step + 1 < n_step) stage_load(step + 1);
@@ -221,6 +243,8 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       if (!region_contains(rg, wi_step, WIN_COLS)) move_region(wi_step, false);
       key_consts(lane, hi ? sb1.amin : sb0.amin);   // lane = key
     }
+    PROF_TD(t1, 0.f);
+    PROF_ADD(0, t1 - t0);
 
 #pragma unroll
     for (int ks = 0; ks < KT / 32; ++ks) {
@@ -234,6 +258,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
           key_consts(ks * 32 + lq, sbh.amin);   // lane & 31 = key (both lane halves write the same value)
         }
       }
+      PROF_TD(t2, 0.f);
       Frag<PREC> kf, vf;
       kf.load(base + (ks * 32 + lq) * L::K_STRIDE, hi);
       load_perm(vf, base + L::K_BYTES + lq * L::V_STRIDE + ks * 32 * EB, hi);
@@ -251,6 +276,8 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
         s = mma_frag(kf, qf, s);
       }
 
+      PROF_TD(t3, s[0] + s[15]);
+      PROF_ADD(1, t3 - t2);
       // relative-position bias: rows of the tile are keys crow(r, hi); lanes are BEV rows i0 + lq.
       if (use_win) {
         const char* wl = win + lqe;
@@ -285,6 +312,8 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
           s[r] += u0 + fx * (u1 - u0);
         }
       }
+      PROF_TD(t4, s[0] + s[15] + s[7]);
+      PROF_ADD(2, t4 - t3);
       // mask padded keys (only the last step can hold any)
       if (step == n_step - 1 && d.N < d.Np) {
 #pragma unroll
@@ -315,12 +344,26 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
         ls2 += pp;
       }
       l += ls2[0] + ls2[1];
+      PROF_TD(t5, l + s[3]);
+      PROF_ADD(3, t5 - t4);
       o = mma_acc_b(vf, s, o);
+      PROF_TD(t6, o[0] + o[15]);
+      PROF_ADD(4, t6 - t5);
     }
+    PROF_TD(t7, 0.f);
 
     if (step + 1 < n_step) stage_store(buf ^ 1, step + 1);
     __syncthreads();
+    PROF_TD(t8, 0.f);
+    PROF_ADD(5, t8 - t7);
+    PROF_ADD(6, t8 - t0);
+    PROF_ADD(7, 1);
   }
+#ifdef BEVR_PROF
+  if (lane == 0 && (wave == 0 || wave == NWF - 1)) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof_fwd[(wave ? 8 : 0) + i], pacc[i]);
+  }
+#endif
 
   // ---- epilogue: normalise, store O^T tile as [q][32] rows and the log2-sum-exp ------------------
   if (jcol < d.S) {

@@ -85,7 +85,7 @@ __device__ __forceinline__ float lane_below(float x) {
 }
 
 // Fixed-point accumulation cell: 64-bit in both precision modes.
-//   unit = bound * 2^-30, bound >= max |dS| over all pairs (handed in by the caller as grad_scale);
+//   unit = ln2 * bound * 2^-30, bound >= max |P (dP - delta)| over all pairs (handed in by the caller as grad_scale);
 //   one contribution converts to a 32-bit integer (v_cvt_rpi, round to nearest: truncation would bias the sum of
 //   many small same-sign contributions) and is sign-extended into the 64-bit cell, so a cell can take 2^32
 //   contributions of the largest possible size before it wraps -- more than a launch has pairs per cell.
@@ -96,10 +96,10 @@ __device__ __forceinline__ float lane_below(float x) {
 //   ds_add_f32 / ds_pk_add_bf16 retire ~3 clk per active LANE (193 clk per wave instruction; tools/micro/lds_bench.hip).
 struct AccCell {
   typedef unsigned long long type;
-  static __device__ __forceinline__ type from(float x) {
-    const int v = cvt_rpi(x);
+  static __device__ __forceinline__ type from_int(int v) {
     return ((unsigned long long)(unsigned)(v >> 31) << 32) | (unsigned)v;
   }
+  static __device__ __forceinline__ type from(float x) { return from_int(cvt_rpi(x)); }
   // whole 64-bit value at once: converting the halves separately rounds the low word of a small NEGATIVE sum
   // (hi = -1, lo = 2^32 - k) to a multiple of 256 units before the halves cancel -- up to 128 units of error per
   // flushed cell, which over the thousands of flushes a table entry receives was 1.3 % of the S = 200 table gradient
@@ -125,7 +125,9 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   static_assert(NCOL == QCOLS, "group_width() assumes this tile width");
   // separate LDS objects: loads of the staged tiles / table window may be scheduled across the window atomics
   __shared__ __attribute__((aligned(16))) char smem[L::BUF];
-  __shared__ __attribute__((aligned(16))) char win[L::WIN];
+  // 256-byte aligned: ds_read2st64_b32 counts its two offsets in units of 256 bytes, so a remainder of the window's
+  // base address would cost one v_add per key row
+  __shared__ __attribute__((aligned(256))) char win[L::WIN];
   typedef AccCell Acc;
   typedef typename Acc::type acc_t;
   __shared__ __attribute__((aligned(16))) acc_t accw[L::WCOLS * WIN_PITCH];
@@ -169,8 +171,10 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   const int j_first = cb * NCOL;
   const int j_last = min(j_first + NCOL - 1, d.S - 1);
   const float jrx_lo = (float)j_first * rx, jrx_hi = (float)j_last * rx;
-  // dS = ln2 * P * (dP - delta): the ln2 is folded into the fixed-point scale here and into dQ at the end
-  const float gscale = grad_scale[0] * BEVR_LN2, ginv = grad_scale[1];
+  // dS = ln2 * P * (dP - delta).  The fixed-point scale 2^e of the table-gradient cells (a power of two: exact) is
+  // folded into dO and delta when they are loaded, so P (dP - delta) comes out of the loop already in cell units;
+  // the ln2 and 2^-e are applied once per flushed cell and once per dQ element.
+  const float gscale = grad_scale[0], ginv = grad_scale[1] * BEVR_LN2;
 
   // this wave's query column; this lane's query row.  Lanes 0..30 of each half carry the tile's 31 queries, lane 31
   // none: its slot is the 32nd table row the tile's taps reach (query 30's lower tap), which lets every lane add the
@@ -197,6 +201,21 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
       for (int k = 0; k < 16; ++k) dof.v[k] = 0.f;
     }
     dlt = 0.f;
+  }
+  dlt *= gscale;
+  if constexpr (PREC == BEVR_PREC_BF16) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4 w = __builtin_bit_cast(u32x4, dof.v[h]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        w[k] = pack_bf16x2(__builtin_bit_cast(float, w[k] << 16) * gscale,
+                           __builtin_bit_cast(float, w[k] & 0xffff0000u) * gscale);
+      dof.v[h] = __builtin_bit_cast(bf16x8, w);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dof.v[k] *= gscale;
   }
   if constexpr (PREC == BEVR_PREC_BF16) {   // own lanes' data, written and read by this wave only
     u32x4* qd = reinterpret_cast<u32x4*>(qdo) + col * 2 * 64 + lane;
@@ -481,20 +500,32 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
             // upper tap of query l and the lower tap of the query above it); lane l adds exactly that, lane 31 the
             // lower tap of query 30 alone (its own dS is 0), lane 0 / lane 32 get 0 from below (wave_shr zero fill /
             // lane 31's zero).  One 64-bit fixed-point add per table column: order-free, bit-reproducible.
-            const float g = ds * gscale;
+            const float g = ds;   // already in cell units (dO and delta carry the scale)
             const float gb_ = lane_below(g);
-            float hA, hB;
-            if constexpr (PREC == BEVR_PREC_BF16) {   // the weights the bias was computed with; dS in bf16 as for dQ
-              const bf16x2 pr = __builtin_bit_cast(bf16x2, pack_bf16x2(g, gb_));
-              hA = __builtin_amdgcn_fdot2_f32_bf16(pr, __builtin_bit_cast(bf16x2, e0.wA), 0.f, false);
-              hB = __builtin_amdgcn_fdot2_f32_bf16(pr, __builtin_bit_cast(bf16x2, e0.wB), 0.f, false);
-            } else {
-              hA = fmaf(gb_, e0.w01(), g * e0.w00());
-              hB = fmaf(gb_, e0.w11(), g * e0.w10());
-            }
             acc_t* gp = accw + (e0.cell + lq);
-            atomicAdd(gp, Acc::from(hA));
-            atomicAdd(gp + WIN_PITCH, Acc::from(hB));
+            if constexpr (PREC == BEVR_PREC_BF16) {   // the weights the bias was computed with; dS in bf16 as for dQ
+              // Both dot products and both round-to-integer conversions as ONE asm block: the VOP3P dot product takes
+              // its zero addend inline (the compiler only selects v_dot2c, which needs a zeroed register first) and
+              // v_cvt_rpi_i32_f32 = floor(x + 0.5) rounds and converts in one instruction -- 4 VALU instead of 8 in a
+              // VALU-bound loop.  The s_nop is the dot -> dependent-VALU wait the hazard recognizer cannot insert for
+              // instructions it does not see (without it the conversion read stale data).
+              const unsigned pr = pack_bf16x2(g, gb_);
+              int iA, iB;
+              asm("v_dot2_f32_bf16 %0, %2, %3, 0\n\t"
+                  "v_dot2_f32_bf16 %1, %2, %4, 0\n\t"
+                  "s_nop 2\n\t"
+                  "v_cvt_rpi_i32_f32 %0, %0\n\t"
+                  "v_cvt_rpi_i32_f32 %1, %1"
+                  : "=&v"(iA), "=&v"(iB)
+                  : "v"(pr), "v"(e0.wA), "v"(e0.wB));
+              atomicAdd(gp, Acc::from_int(iA));
+              atomicAdd(gp + WIN_PITCH, Acc::from_int(iB));
+            } else {
+              const float hA = fmaf(gb_, e0.w01(), g * e0.w00());
+              const float hB = fmaf(gb_, e0.w11(), g * e0.w10());
+              atomicAdd(gp, Acc::from(hA));
+              atomicAdd(gp + WIN_PITCH, Acc::from(hB));
+            }
             e0 = e1; e1 = e2; ta = na; tb = nb;
           }
         }
@@ -555,7 +586,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
             // plain transposed table, row pitch Hp + 1
             int yi = (c.aoff >> 3) - xoffHp + ilane;
             float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
-            float w0 = BEVR_LN2 * ds * (1.0f - fx), w1 = BEVR_LN2 * ds * fx;
+            float w0 = ginv * ds * (1.0f - fx), w1 = ginv * ds * fx;   // ginv = ln2 2^-e
             atomicAdd(g0, w0 * wy0);
             atomicAdd(g0 + 1, w0 * c.fy);
             atomicAdd(g0 + Hq, w1 * wy0);
@@ -579,14 +610,14 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
 #endif
   flush_and_clear(rg);
 
-  // ---- store dQ (ln2 of dS = ln2 P (dP - delta) applied here) -----------------------------------------------
+  // ---- store dQ (ln2 of dS = ln2 P (dP - delta) and the 2^-e of the cell scale applied here) -----------------------------------------------
   if (live) {
     float* row = dQ + ((size_t)ph * Mp + (size_t)jcol * d.Sp + qrow) * 32;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = BEVR_LN2 * dq[4 * g4 + k];
+      for (int k = 0; k < 4; ++k) v[k] = ginv * dq[4 * g4 + k];
       *reinterpret_cast<f32x4*>(row + 8 * g4 + 4 * hi) = v;
     }
   }

@@ -281,16 +281,46 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       // relative-position bias: rows of the tile are keys crow(r, hi); lanes are BEV rows i0 + lq.
       if (use_win) {
         const char* wl = win + lqe;
+        if constexpr (PREC == BEVR_PREC_BF16) {
+          // hand-pipelined, BIAS_BATCH key rows at a time: all cell reads, then all tap and weight reads, then the dot
+          // products -- two LDS latencies per batch instead of two per two or three rows (the compiler's own schedule)
+#ifndef BEVR_BIAS_BATCH
+#define BEVR_BIAS_BATCH 8
+#endif
+          constexpr int BIAS_BATCH = BEVR_BIAS_BATCH;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const CK e = pck[ks * 32 + crow(r, hi)];
-          const char* p = wl + e.cell;
-          if constexpr (PREC == BEVR_PREC_BF16) {
-            const bf16x2 t0 = __builtin_bit_cast(bf16x2, *reinterpret_cast<const unsigned*>(p));
-            const bf16x2 t1 = __builtin_bit_cast(bf16x2, *reinterpret_cast<const unsigned*>(p + WIN_PITCH * ENT));
-            float sv = __builtin_amdgcn_fdot2_f32_bf16(t0, __builtin_bit_cast(bf16x2, e.wA), s[r], false);
-            s[r] = __builtin_amdgcn_fdot2_f32_bf16(t1, __builtin_bit_cast(bf16x2, e.wB), sv, false);
-          } else {
+          for (int r0 = 0; r0 < 16; r0 += BIAS_BATCH) {
+            // scalars, not 2-vectors: ROCm 7.2 feeds element 0 of a 2-vector to both dot products
+            int cell[BIAS_BATCH];
+            unsigned wa[BIAS_BATCH], wb[BIAS_BATCH], ta[BIAS_BATCH], tb[BIAS_BATCH];
+#pragma unroll
+            for (int k = 0; k < BIAS_BATCH; ++k) {
+              const CK& e = pck[ks * 32 + crow(r0 + k, hi)];
+              cell[k] = e.cell;
+              wa[k] = e.wA;
+              wb[k] = e.wB;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < BIAS_BATCH; ++k) {
+              const char* p = wl + cell[k];
+              ta[k] = *reinterpret_cast<const unsigned*>(p);
+              tb[k] = *reinterpret_cast<const unsigned*>(p + WIN_PITCH * ENT);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < BIAS_BATCH; ++k) {
+              float sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ta[k]),
+                                                         __builtin_bit_cast(bf16x2, wa[k]), s[r0 + k], false);
+              s[r0 + k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, tb[k]),
+                                                          __builtin_bit_cast(bf16x2, wb[k]), sv, false);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const CK e = pck[ks * 32 + crow(r, hi)];
+            const char* p = wl + e.cell;
             const f32x2 t0 = *reinterpret_cast<const f32x2*>(p);
             const f32x2 t1 = *reinterpret_cast<const f32x2*>(p + WIN_PITCH * ENT);
             s[r] = fmaf(t1[1], e.w11(), fmaf(t1[0], e.w10(), fmaf(t0[1], e.w01(), fmaf(t0[0], e.w00(), s[r]))));

@@ -283,9 +283,10 @@ class _AttnCore(torch.autograd.Function):
         dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
         Kt = _perm_t(Ke)
         # fixed-point scale of the in-LDS table-gradient accumulation (include/bevrender_hip.h): a power of two s with
-        # s * bound(|dS|) <= 2^30.  dS = ln2 P (dP - delta), P <= 1, |dP| = |dO_q . V_n| <= ||dO_q|| ||V_n||:
-        # bound = ln2 (max_q ||dO_q|| max_n ||V_n|| + max |delta|).  Stays on the device (no sync).
-        bound = math.log(2.0) * (dOe.float().norm(dim=-1).max() * Ve.float().norm(dim=-1).max() + delta.abs().max())
+        # s * bound <= 2^30, bound >= |P (dP - delta)| of every pair: P <= 1, |dP| = |dO_q . V_n| <= ||dO_q|| ||V_n||,
+        # so bound = max_q ||dO_q|| max_n ||V_n|| + max |delta|.  The kernel applies s to dO and delta as it loads
+        # them (exact: a power of two) and ln2 / s when it stores.  Stays on the device (no sync).
+        bound = dOe.float().norm(dim=-1).max() * Ve.float().norm(dim=-1).max() + delta.abs().max()
         e = torch.floor(30.0 - torch.log2(bound.clamp_min(1e-30))).clamp(-100.0, 100.0)
         gscale = torch.stack((torch.exp2(e), torch.exp2(-e))).contiguous()
         _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(geom, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),

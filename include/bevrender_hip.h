@@ -118,11 +118,12 @@ int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const v
  *   it is ACCUMULATED into (caller zeroes it).
  *   V  [n_prob][heads][Np][32] E (row layout), Kt [like Vt] E, dO [n_prob][heads][Mp][32] E,
  *   delta [n_prob][heads][Mp] float = rowsum(dO * O).
- *   grad_scale [2] float (device): { s, 1/s } with s a power of two such that s * max|dS| <= 2^30, where
- *   dS = ln2 * P * (dP - delta); a valid bound is ln2 * (max_q |dO_q| * max_n |V_n| + max |delta|) (Euclidean
- *   norms over the 32 channels; P <= 1).  The kernel accumulates the table gradient in 64-bit fixed point with
- *   unit 1/s (each contribution rounded to nearest; sums are exact and order-independent within a workgroup's
- *   window, and a cell cannot wrap: 2^33 contributions of the largest size fit).
+ *   grad_scale [2] float (device): { s, 1/s } with s a power of two such that s * max|P (dP - delta)| <= 2^30; a
+ *   valid bound is max_q |dO_q| * max_n |V_n| + max |delta| (Euclidean norms over the 32 channels; P <= 1).  The
+ *   kernel multiplies dO and delta by s as it loads them (exact) and accumulates the table gradient in 64-bit fixed
+ *   point with unit ln2 / s (each contribution rounded to nearest; sums are exact and order-independent within a
+ *   workgroup's window, and a cell cannot wrap: 2^33 contributions of the largest size fit); ln2 / s is applied
+ *   when a cell is flushed and when dQ is stored.
  *   All gradients are with respect to the log2-domain logits' inputs as handed in (Q pre-scaled,
  *   table pre-multiplied): the caller's autograd undoes the scaling. */
 int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,

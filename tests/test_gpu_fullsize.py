@@ -293,27 +293,40 @@ def test_encoder_layer_s56_matches_reference(prec):
     print(f"[enclayer s56 prec={prec}] worst sampled gradient err/absmax {worst:.3e}")
 
 
-def test_cfg5_geometry_bev400_rows_forward():
+def test_cfg5_geometry_bev400_rows_and_gradients():
     """The S = 400 geometry of BASELINE config 5 (M = 160 000, N = 400 000 per view, table 799 x 3999), one view,
     bf16 operands (the kernels have bf16 and f32 operand modes; fp16 inputs are served in bf16):
-    64 random query rows against the oracle, and constant V => every row returns that constant."""
+    64 random query rows against the float64 oracle -- forward and, with a cotangent that is zero elsewhere, every
+    gradient -- and constant V => every row returns that constant."""
     S, D, C, h = 400, 5, 64, 2
     p = lift_problem(S, D, 1, C, h, 1408, 512, {"X": 50, "Y": 50, "Z": 2}, seed=400, table_std=0.3)
     rows = pick_rows(S, 64, 2)
-    want, _ = oracle_rows(p, h, rows, None, want_grads=False)
-    ins = {n: p[n].to(DEV) for n in ("query", "k", "v", "pos", "table")}
+    cot = torch.randn(1, len(rows), C, generator=torch.Generator().manual_seed(6))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    want, grads = oracle_rows(p, h, rows, cot)
+    ins = {n: p[n].clone().to(DEV).requires_grad_(True) for n in ("query", "k", "v", "pos", "table")}
     out = ops.attention_core(ins["query"], ins["k"], ins["v"], ins["pos"], ins["table"], heads=h, groups=1, views=1,
                              precision=_lib.PREC_BF16)
+    cot_full = torch.zeros_like(out)
+    cot_full[:, rows.to(DEV)] = cot.to(DEV)
+    out.backward(cot_full)
     torch.cuda.synchronize()
-    e = rel_err(out[:, rows.to(DEV)].cpu(), want)
+    lim = LIMITS[_lib.PREC_BF16]
+    e = rel_err(out.detach()[:, rows.to(DEV)].cpu(), want)
     print(f"\n[cfg5 geometry bf16] out rel err {e:.3e}")
-    assert e < 1.5e-2
-    pat = torch.randn(C, generator=torch.Generator().manual_seed(1)).to(DEV)
-    vconst = pat[None, None, :].expand_as(ins["v"]).contiguous()
-    out = ops.attention_core(ins["query"], ins["k"], vconst, ins["pos"], ins["table"], heads=h, groups=1, views=1,
-                             precision=_lib.PREC_BF16)
-    torch.cuda.synchronize()
-    assert (out - pat.to(torch.bfloat16).float()).abs().max().item() < 2e-2
+    assert e < lim["out"]
+    for n in ("query", "k", "v", "table"):
+        e = rel_err(ins[n].grad.cpu(), grads[n])
+        print(f"[cfg5 geometry bf16] grad {n:6s} rel err {e:.3e}  (max |want| {grads[n].abs().max().item():.3e})")
+        assert e < lim[n], f"grad {n}: {e:.3e}"
+    check_dpos(ins["pos"].grad, grads["pos"], p["pos"], S, p["table"].shape[-1], lim["pos"], "cfg5 bf16")
+    with torch.no_grad():
+        pat = torch.randn(C, generator=torch.Generator().manual_seed(1)).to(DEV)
+        vconst = pat[None, None, :].expand_as(ins["v"]).contiguous()
+        out = ops.attention_core(ins["query"].detach(), ins["k"].detach(), vconst, ins["pos"].detach(),
+                                 ins["table"].detach(), heads=h, groups=1, views=1, precision=_lib.PREC_BF16)
+        torch.cuda.synchronize()
+        assert (out - pat.to(torch.bfloat16).float()).abs().max().item() < 2e-2
 
 
 @pytest.mark.parametrize("B", [2, 8])

@@ -27,7 +27,7 @@ SYMBOLS = [
     "bevr_attn_fwd", "bevr_attn_bwd_q",
     "bevr_attn_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_project_bev_grid", "bevr_project_bev_grid_masked", "bevr_corr_fwd",
     "bevr_corr_bwd", "bevr_recall_rank", "bevr_dwconv_fwd", "bevr_dwconv_bwd_w", "bevr_affine_warp_fwd", "bevr_affine_warp_bwd",
-    "bevr_offset_head_fwd", "bevr_offset_head_bwd",
+    "bevr_offset_head_fwd", "bevr_offset_head_bwd", "bevr_pack_kv", "bevr_unpack_dkv",
 ]
 
 
@@ -95,6 +95,8 @@ def lib() -> C.CDLL:
         L.bevr_affine_warp_bwd.argtypes = [fp, fp, fp] + [ip] * 4 + [vp]
         L.bevr_offset_head_fwd.argtypes = [fp] * 7 + [C.c_longlong] + [ip] * 4 + [C.c_float, vp]
         L.bevr_offset_head_bwd.argtypes = [fp] * 13 + [C.c_longlong] + [ip] * 4 + [C.c_float, vp]
+        L.bevr_pack_kv.argtypes = [fp, fp, C.c_longlong] + [ip] * 6 + [vp] * 5
+        L.bevr_unpack_dkv.argtypes = [fp] * 4 + [C.c_longlong] + [ip] * 5 + [vp]
         for name in SYMBOLS:
             fn = getattr(L, name)
             if name == "bevr_attn_key_ws_bytes":

@@ -40,7 +40,6 @@ __device__ __forceinline__ unsigned long long prof_now(float dep) {
 
 namespace {
 
-constexpr int QT = 32;          // queries per iteration (one 32-row block of one BEV column)
 constexpr int KEYS_WG = 384;    // keys per workgroup, both kernels: the unit of ownership
 
 // bounding box of a key block in table coordinates (padded keys excluded)

@@ -1,0 +1,130 @@
+// Operand packing for the attention kernels, and its transpose for the key-side gradients.
+//
+// The K/V projections of the sampled features come out of rocBLAS as rows (B', N, C) of float (one GEMM emits K | V
+// side by side, so a row stride is taken); the attention kernels read
+//   row layout        X [B'][h][Np][32] E      (E = bf16 or float; head_dim c <= 32 zero padded, keys N..Np-1 zero)
+//   transposed layout Xt[B'][h][32][Np] E      with bits 2 <-> 3 of the in-32 key index swapped (bevr_common.h: the
+//                                               order in which an MFMA accumulator tile is consumed as a B operand)
+// The stock-op chain for this (reshape/permute/pad copy, dtype copy, index_select, transpose copy, per tensor) moved
+// ~12 GB per SCA call at B = 8 for 2.5 GB of input; one pass here reads the rows once and writes each layout once.
+// Reference: the reshapes of model/SCA_deform_attn.py:312-321 (proj_k / proj_v outputs -> (B h, c, N)).
+#include "bevr_common.h"
+
+namespace {
+
+constexpr int PK = 64;   // keys per workgroup tile
+
+__device__ __forceinline__ int perm32(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+template <typename E> __device__ __forceinline__ E to_elem(float x);
+template <> __device__ __forceinline__ float to_elem<float>(float x) { return x; }
+template <> __device__ __forceinline__ unsigned short to_elem<unsigned short>(float x) {
+  return (unsigned short)(pack_bf16x2(x, 0.f) & 0xffffu);   // round to nearest even, as torch's .to(bfloat16)
+}
+
+// One workgroup = 64 consecutive keys of one problem, all heads, K and V.
+template <typename E>
+__global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
+                                                      long long ld, int N, int Np, int heads, int c,
+                                                      E* __restrict__ Kr, E* __restrict__ Vr, E* __restrict__ Kt,
+                                                      E* __restrict__ Vt) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  E* tile = reinterpret_cast<E*>(smem_raw);   // [kind 2][head][key 64][32]
+  const int b = blockIdx.y, n0 = blockIdx.x * PK, tid = threadIdx.x;
+  const int C = heads * c;
+  const int n_el = 2 * heads * PK * 32;
+  if (c < 32 || n0 + PK > N) {   // zero padding (channels c..31, keys past N)
+    for (int i = tid; i < n_el; i += 256) tile[i] = to_elem<E>(0.f);
+    __syncthreads();
+  }
+  const float* src[2] = {k + (size_t)b * N * ld, v + (size_t)b * N * ld};
+#pragma unroll
+  for (int kind = 0; kind < 2; ++kind) {
+    for (int i = tid; i < PK * C; i += 256) {
+      const int key = i / C, ch = i - key * C;
+      if (n0 + key < N) {
+        const float x = src[kind][(size_t)(n0 + key) * ld + ch];
+        tile[((kind * heads + ch / c) * PK + key) * 32 + ch % c] = to_elem<E>(x);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int EPC = 16 / sizeof(E);      // elements per 16-byte chunk
+  constexpr int CPR = 32 / EPC;            // chunks per 32-element row
+  // row layout: (head, key) rows of 32 elements, 64 keys contiguous per head
+  for (int i = tid; i < 2 * heads * PK * CPR; i += 256) {
+    const int chunk = i % CPR, key = (i / CPR) % PK, hk = i / (CPR * PK);   // hk = kind * heads + head
+    const int kind = hk / heads, head = hk - kind * heads;
+    E* dst = (kind ? Vr : Kr) + (((size_t)b * heads + head) * Np + n0 + key) * 32 + chunk * EPC;
+    *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(tile + (hk * PK + key) * 32 + chunk * EPC);
+  }
+  // transposed layout: (head, channel) rows of Np keys; this tile's 64 keys are contiguous, permuted inside each 32
+  constexpr int CPT = PK / EPC;            // chunks per (head, channel) row segment of the tile
+  for (int i = tid; i < 2 * heads * 32 * CPT; i += 256) {
+    const int chunk = i % CPT, ch = (i / CPT) % 32, hk = i / (CPT * 32);
+    const int kind = hk / heads, head = hk - kind * heads;
+    E* dbase = kind ? Vt : Kt;
+    if (!dbase) continue;
+    E tmp[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int l = chunk * EPC + e;                       // position inside the tile
+      const int keyp = (l & ~31) + perm32(l & 31);         // Xt[.., ch, l] = X[.., perm(l), ch]
+      tmp[e] = tile[(hk * PK + keyp) * 32 + ch];
+    }
+    E* dst = dbase + (((size_t)b * heads + head) * 32 + ch) * Np + n0 + chunk * EPC;
+    u32x4 w;
+    __builtin_memcpy(&w, tmp, 16);
+    *reinterpret_cast<u32x4*>(dst) = w;
+  }
+}
+
+// dK, dV [B'][h][Np][32] float (row layout) -> dk, dv rows (B', N, C) with row stride ld
+__global__ __launch_bounds__(256) void unpack_dkv_kernel(const float* __restrict__ dK, const float* __restrict__ dV,
+                                                         float* __restrict__ dk, float* __restrict__ dv, long long ld,
+                                                         int N, int Np, int heads, int c) {
+  const int b = blockIdx.y, n0 = blockIdx.x * PK, tid = threadIdx.x;
+  const int C = heads * c;
+  for (int i = tid; i < PK * C; i += 256) {
+    const int key = i / C, ch = i - key * C;
+    if (n0 + key >= N) continue;
+    const size_t s = (((size_t)b * heads + ch / c) * Np + n0 + key) * 32 + ch % c;
+    const size_t o = ((size_t)b * N + n0 + key) * ld + ch;
+    dk[o] = dK[s];
+    dv[o] = dV[s];
+  }
+}
+
+}  // namespace
+
+extern "C" int bevr_pack_kv(const float* k, const float* v, long long ld, int n_prob, int N, int Np, int heads, int c,
+                            int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream) {
+  if (!k || !v || !Kr || !Vr) return BEVR_E_NULL;
+  if (n_prob <= 0 || N <= 0 || Np < N || Np % PK || heads <= 0 || c <= 0 || c > 32 || ld < (long long)heads * c)
+    return BEVR_E_SHAPE;
+  if (precision != BEVR_PREC_BF16 && precision != BEVR_PREC_F32) return BEVR_E_PRECISION;
+  if (!bevr_aligned16(Kr) || !bevr_aligned16(Vr) || (Kt && !bevr_aligned16(Kt)) || (Vt && !bevr_aligned16(Vt)))
+    return BEVR_E_ALIGN;
+  const dim3 grid(Np / PK, n_prob);
+  const size_t eb = precision == BEVR_PREC_BF16 ? 2 : 4;
+  const size_t lds = (size_t)2 * heads * PK * 32 * eb;
+  if (lds > 64 * 1024) return BEVR_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  if (precision == BEVR_PREC_BF16)
+    hipLaunchKernelGGL(pack_kv_kernel<unsigned short>, grid, dim3(256), lds, st, k, v, ld, N, Np, heads, c,
+                       (unsigned short*)Kr, (unsigned short*)Vr, (unsigned short*)Kt, (unsigned short*)Vt);
+  else
+    hipLaunchKernelGGL(pack_kv_kernel<float>, grid, dim3(256), lds, st, k, v, ld, N, Np, heads, c, (float*)Kr,
+                       (float*)Vr, (float*)Kt, (float*)Vt);
+  return (int)hipGetLastError();
+}
+
+extern "C" int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, int n_prob, int N,
+                               int Np, int heads, int c, void* stream) {
+  if (!dK || !dV || !dk || !dv) return BEVR_E_NULL;
+  if (n_prob <= 0 || N <= 0 || Np < N || Np % PK || heads <= 0 || c <= 0 || c > 32 || ld < (long long)heads * c)
+    return BEVR_E_SHAPE;
+  hipLaunchKernelGGL(unpack_dkv_kernel, dim3(Np / PK, n_prob), dim3(256), 0, (hipStream_t)stream, dK, dV, dk, dv, ld,
+                     N, Np, heads, c);
+  return (int)hipGetLastError();
+}

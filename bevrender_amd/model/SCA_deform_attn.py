@@ -118,9 +118,8 @@ class SCADeformableAttention(nn.Module):
         # read once instead of twice)
         kv = F.linear(xs, torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0),
                       torch.cat((self.proj_k.bias, self.proj_v.bias), 0))
-        k, v = kv.split(kv.shape[-1] // 2, dim=-1)
-        o = ops.attention_core(query, k, v, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
-                               precision=self.precision)                         # (B*V, S*S, C)
+        o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
+                               precision=self.precision, kv=kv)                  # (B*V, S*S, C)
         o = o.reshape(B, V, S * S, C).permute(0, 2, 1, 3).reshape(B, S * S, V * C)
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
         return out.permute(0, 2, 1).reshape(B, C, S, S), wandb_log_dict

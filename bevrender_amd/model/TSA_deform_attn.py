@@ -102,9 +102,8 @@ class TSADeformableAttention(nn.Module):
         # read once instead of twice)
         kv = F.linear(xs, torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0),
                       torch.cat((self.proj_k.bias, self.proj_v.bias), 0))
-        k, v = kv.split(kv.shape[-1] // 2, dim=-1)
-        o = ops.attention_core(query, k, v, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
-                               views=1, precision=self.precision)                        # (B, H*W, C)
+        o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
+                               views=1, precision=self.precision, kv=kv)                 # (B, H*W, C)
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
         out = out.permute(0, 2, 1).reshape(B, C, H, W)
         return out, wandb_log_dict

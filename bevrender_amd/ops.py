@@ -244,12 +244,24 @@ class _AttnCore(torch.autograd.Function):
     """O = softmax(Q K^T + bias(a, b, table)) V in packed layouts (all inputs float32)."""
 
     @staticmethod
-    def forward(ctx, Qp, Kp, Vp, key_a, key_b, Tt, geom: AttnGeom):
-        _require_gpu(Qp, Kp, Vp, key_a, key_b, Tt)
+    def forward(ctx, Qp, kv, key_a, key_b, Tt, geom: AttnGeom):
+        _require_gpu(Qp, kv, key_a, key_b, Tt)
         L = _lib.lib()
         ed = _edtype(geom.precision)
-        Qe, Ke, Ve = Qp.to(ed).contiguous(), Kp.to(ed).contiguous(), Vp.to(ed).contiguous()
-        Vt = _perm_t(Ve)
+        Qe = Qp.to(ed).contiguous()
+        # K | V rows (B', N, 2 h c) float -> the kernels' per-head layouts in one pass (csrc/pack.hip); the transposed K
+        # is only read by the backward
+        kv = kv.float().contiguous()
+        C2 = kv.shape[-1]
+        c = C2 // 2 // geom.heads
+        dev = Qp.device
+        Ke = torch.empty(geom.n_prob, geom.heads, geom.Np, HEAD_DIM, device=dev, dtype=ed)
+        Ve = torch.empty_like(Ke)
+        Vt = torch.empty(geom.n_prob, geom.heads, HEAD_DIM, geom.Np, device=dev, dtype=ed)
+        Kt = torch.empty_like(Vt) if any(ctx.needs_input_grad) else None
+        _lib.check(L.bevr_pack_kv(_ptr(kv), C.c_void_p(kv.data_ptr() + 2 * C2), C2, geom.n_prob, geom.N, geom.Np,
+                                  geom.heads, c, geom.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _stream()),
+                   "bevr_pack_kv")
         key_a, key_b = key_a.contiguous(), key_b.contiguous()
         Ttc = Tt.contiguous()
         pair = torch.stack((Ttc[..., :-1], Ttc[..., 1:]), dim=-1).contiguous()   # (h, Wp, Hp, 2)
@@ -264,13 +276,14 @@ class _AttnCore(torch.autograd.Function):
                                     _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O), _ptr(LSE),
                                     _stream()), "bevr_attn_fwd")
         ctx.geom = geom
-        ctx.save_for_backward(Qe, Ke, Ve, key_a, key_b, pair, O, LSE, key_ws)
+        ctx.kv_shape = kv.shape
+        ctx.save_for_backward(Qe, Ke, Ve, Kt, key_a, key_b, pair, O, LSE, key_ws)
         return O
 
     @staticmethod
     def backward(ctx, dO):
         geom: AttnGeom = ctx.geom
-        Qe, Ke, Ve, key_a, key_b, pair, O, LSE, key_ws = ctx.saved_tensors
+        Qe, Ke, Ve, Kt, key_a, key_b, pair, O, LSE, key_ws = ctx.saved_tensors
         L = _lib.lib()
         ed = _edtype(geom.precision)
         dO = dO.contiguous()
@@ -281,7 +294,6 @@ class _AttnCore(torch.autograd.Function):
         # zeros: bwd_q walks the grid in 31-row tiles and never visits the padded rows S..Sp-1 of a column
         dQ = torch.zeros(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
         dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
-        Kt = _perm_t(Ke)
         # fixed-point scale of the in-LDS table-gradient accumulation (include/bevrender_hip.h): a power of two s with
         # s * bound <= 2^30, bound >= |P (dP - delta)| of every pair: P <= 1, |dP| = |dO_q . V_n| <= ||dO_q|| ||V_n||,
         # so bound = max_q ||dO_q|| max_n ||V_n|| + max |delta|.  The kernel applies s to dO and delta as it loads
@@ -306,31 +318,43 @@ class _AttnCore(torch.autograd.Function):
                                     _stream()), "bevr_attn_bwd_k")
         if geom.q_div > 1:  # the views of one sample share the query: sum their query gradients
             dQ = dQ.reshape(geom.n_prob // geom.q_div, geom.q_div, geom.heads, geom.Mp, HEAD_DIM).sum(1)
-        return dQ, dK, dV, da, db, dT, None
+        # gradients of the row layout back to K | V rows (the adjoint of the packing)
+        dkv = torch.empty(ctx.kv_shape, device=dev, dtype=torch.float32)
+        C2 = dkv.shape[-1]
+        _lib.check(L.bevr_unpack_dkv(_ptr(dK), _ptr(dV), _ptr(dkv), C.c_void_p(dkv.data_ptr() + 2 * C2), C2,
+                                     geom.n_prob, geom.N, geom.Np, geom.heads, C2 // 2 // geom.heads, _stream()),
+                   "bevr_unpack_dkv")
+        return dQ, dkv, da, db, dT, None
 
 
-def attention_core(query: torch.Tensor, kproj: torch.Tensor, vproj: torch.Tensor, pos: torch.Tensor,
-                   rpe_table: torch.Tensor, *, heads: int, groups: int, views: int, precision: int) -> torch.Tensor:
+def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Optional[torch.Tensor], pos: torch.Tensor,
+                   rpe_table: torch.Tensor, *, heads: int, groups: int, views: int, precision: int,
+                   kv: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused attention of the BEV query against sampled keys.
 
     query (B, C, S, S) layer-normed BEV query (used raw as Q); kproj, vproj (B*views, N, C) projected
-    sampled features; pos (B*views*groups, N, 2) key positions (y, x); rpe_table (h, 2S-1, Wt).
+    sampled features -- or `kv` (B*views, N, 2C) = K | V side by side, as one GEMM emits them (kproj = vproj = None);
+    pos (B*views*groups, N, 2) key positions (y, x); rpe_table (h, 2S-1, Wt).
     Returns (B*views, S*S, C): per view softmax(QK^T c^-0.5 + bias) V, rows in i*S + j order.
     Replaces model/SCA_deform_attn.py:304-413 / model/TSA_deform_attn.py:220-333.
     """
+    if kv is None:
+        kv = torch.cat((kproj, vproj), -1)
+    elif kproj is not None or vproj is not None:
+        raise ValueError("pass either kproj and vproj, or kv")
     B, Cc, S, _ = query.shape
-    Bp, N, _ = kproj.shape
+    Bp, N, C2 = kv.shape
+    if C2 != 2 * Cc:
+        raise ValueError(f"K | V rows must have 2 x {Cc} channels, got {C2}")
     c = Cc // heads
     geom = AttnGeom(n_prob=Bp, q_div=views, heads=heads, groups=groups, S=S, N=N, Wt=rpe_table.shape[-1],
                     precision=precision)
     if rpe_table.shape[-2] != 2 * S - 1:
         raise ValueError("rpe_table height must be 2S-1")
     Qp = pack_query(query.float(), heads)
-    Kp = pack_keys(kproj.float(), heads)
-    Vp = pack_keys(vproj.float(), heads)
     a, b = key_coords(pos.float(), S, geom.Wt, geom.Np)
     Tt = pack_table(rpe_table.float(), geom)
-    O = _AttnCore.apply(Qp, Kp, Vp, a, b, Tt, geom)
+    O = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom)
     return unpack_out(O, S, c)
 
 

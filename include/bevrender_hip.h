@@ -19,6 +19,7 @@
  *   bevr_sample_fwd/bwd     F.grid_sample at model/SCA_deform_attn.py:290-301, model/TSA_deform_attn.py:210-217
  *   bevr_attn_fwd/bwd_*     model/SCA_deform_attn.py:331-413, model/TSA_deform_attn.py:245-333
  *                           (QK^T*scale + bilinear RPE bias + softmax + PV, never materialised)
+ *   bevr_pack_kv/unpack_dkv model/SCA_deform_attn.py:312-321 (projection outputs -> per-head operand layouts)
  *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
  *   bevr_offset_head_fwd/bwd  model/SCA_deform_attn.py:56-77, model/TSA_deform_attn.py:54-68 (offset heads, fused)
  *   bevr_affine_warp_fwd/bwd  model/encoder.py:413-466 (project_history_bev_feat: torchvision F.affine, twice)
@@ -195,6 +196,21 @@ int bevr_dwconv_fwd(const float* x, const float* w, const float* bias, float* y,
                     int B, int H, int W, int C, int k, int nhwc, int flip, void* stream);
 int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
                       int B, int H, int W, int C, int k, int nhwc, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operand packing for bevr_attn_* (the reshapes of model/SCA_deform_attn.py:312-321 / TSA_deform_attn.py:228-243:
+ * proj_k / proj_v outputs -> per-head operands), one pass instead of a permute / pad / cast / transpose chain.
+ *   k, v  rows (n_prob, N, heads*c) float with row stride ld floats (ld >= heads*c; K | V of one GEMM: ld = 2 heads c)
+ *   Kr, Vr [n_prob][heads][Np][32] E   row layout: head_dim c <= 32 zero padded, keys N..Np-1 zero (Np % 64 == 0)
+ *   Kt, Vt [n_prob][heads][32][Np] E   transposed, bits 2 <-> 3 of the in-32 key index swapped (either may be NULL)
+ *   E = bf16 (BEVR_PREC_BF16, round to nearest even) or float (BEVR_PREC_F32).
+ * bevr_unpack_dkv is the adjoint on the gradients of the row layout: dK, dV [n_prob][heads][Np][32] float ->
+ * dk, dv rows (n_prob, N, heads*c) with row stride ld (every element of the rows written).
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_pack_kv(const float* k, const float* v, long long ld, int n_prob, int N, int Np, int heads, int c,
+                 int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream);
+int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, int n_prob, int N, int Np,
+                    int heads, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Offset heads of the deformable attention blocks, fused per BEV pixel (model/SCA_deform_attn.py:56-77 conv_offset_m{v};

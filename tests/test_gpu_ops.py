@@ -433,3 +433,48 @@ def test_depthwise_conv_matches_torch(shape, nhwc):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16])
+@pytest.mark.parametrize("shape", [(3, 300, 2, 32), (2, 129, 2, 8), (1, 64, 4, 16)])
+def test_pack_kv_equals_the_stock_op_chain_and_unpack_is_its_adjoint(shape, prec):
+    """csrc/pack.hip against the chain it replaces (ops.pack_keys -> dtype cast -> ops._perm_t): bit-identical in both
+    element types, zero padding included; bevr_unpack_dkv returns exactly the rows the packing read."""
+    import ctypes as C
+    Bp, N, h, c = shape
+    Cc = h * c
+    Np = 64 * ((N + 63) // 64)
+    g = torch.Generator().manual_seed(N)
+    kv = torch.randn(Bp, N, 2 * Cc, generator=g).to(DEV)
+    ed = torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float32
+    Kr = torch.full((Bp, h, Np, 32), 7.0, device=DEV, dtype=ed)
+    Vr, Kt, Vt = torch.full_like(Kr, 7.0), torch.full((Bp, h, 32, Np), 7.0, device=DEV, dtype=ed), None
+    Vt = torch.full_like(Kt, 7.0)
+    L = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = L.bevr_pack_kv(p(kv), C.c_void_p(kv.data_ptr() + 4 * Cc), 2 * Cc, Bp, N, Np, h, c, prec, p(Kr), p(Vr), p(Kt),
+                        p(Vt), st)
+    assert rc == 0
+    k, v = kv[..., :Cc], kv[..., Cc:]
+    Kw, Vw = ops.pack_keys(k, h).to(ed).contiguous(), ops.pack_keys(v, h).to(ed).contiguous()
+    assert torch.equal(Kr, Kw) and torch.equal(Vr, Vw)
+    assert torch.equal(Kt, ops._perm_t(Kw)) and torch.equal(Vt, ops._perm_t(Vw))
+    # no transposed outputs requested
+    Kr2, Vr2 = torch.empty_like(Kr), torch.empty_like(Vr)
+    assert L.bevr_pack_kv(p(kv), C.c_void_p(kv.data_ptr() + 4 * Cc), 2 * Cc, Bp, N, Np, h, c, prec, p(Kr2), p(Vr2),
+                          None, None, st) == 0
+    assert torch.equal(Kr2, Kw) and torch.equal(Vr2, Vw)
+    # adjoint on float gradients
+    dK = torch.randn(Bp, h, Np, 32, generator=g).to(DEV)
+    dV = torch.randn(Bp, h, Np, 32, generator=g).to(DEV)
+    dkv = torch.full((Bp, N, 2 * Cc), 7.0, device=DEV)
+    assert L.bevr_unpack_dkv(p(dK), p(dV), p(dkv), C.c_void_p(dkv.data_ptr() + 4 * Cc), 2 * Cc, Bp, N, Np, h, c, st) == 0
+    want_k = dK[:, :, :N, :c].permute(0, 2, 1, 3).reshape(Bp, N, Cc)
+    want_v = dV[:, :, :N, :c].permute(0, 2, 1, 3).reshape(Bp, N, Cc)
+    assert torch.equal(dkv[..., :Cc], want_k) and torch.equal(dkv[..., Cc:], want_v)
+    # argument contract
+    assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, Bp, N, Np + 1, h, c, prec, p(Kr), p(Vr), None, None, st) == -2
+    assert L.bevr_pack_kv(None, p(kv), 2 * Cc, Bp, N, Np, h, c, prec, p(Kr), p(Vr), None, None, st) == -1
+    assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, Bp, N, Np, h, c, 5, p(Kr), p(Vr), None, None, st) == -3

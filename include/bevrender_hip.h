@@ -198,7 +198,7 @@ int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
                       int B, int H, int W, int C, int k, int nhwc, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Operand packing for bevr_attn_* (the reshapes of model/SCA_deform_attn.py:312-321 / TSA_deform_attn.py:228-243:
+ * Operand packing for bevr_attn_* (the reshapes of model/SCA_deform_attn.py:312-321 / TSA_deform_attn.py:226-236:
  * proj_k / proj_v outputs -> per-head operands), one pass instead of a permute / pad / cast / transpose chain.
  *   k, v  rows (n_prob, N, heads*c) float with row stride ld floats (ld >= heads*c; K | V of one GEMM: ld = 2 heads c)
  *   Kr, Vr [n_prob][heads][Np][32] E   row layout: head_dim c <= 32 zero padded, keys N..Np-1 zero (Np % 64 == 0)

@@ -271,7 +271,9 @@ def main():
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
 
     gen = torch.Generator(device=dev).manual_seed(15213 + rank)
-    feats = [torch.randn(B * V, C, Hi, Wi, device=dev, dtype=torch.bfloat16, generator=gen).float() for _ in range(2)]
+    # backbone features as the backbone hands them over: channels-last (the sampler's layout, no copy)
+    feats = [torch.randn(B * V, C, Hi, Wi, device=dev, dtype=torch.bfloat16, generator=gen).float()
+             .contiguous(memory_format=torch.channels_last) for _ in range(2)]
     map_emb = torch.nn.functional.normalize(torch.randn(B, C * S * S, device=dev, generator=gen), dim=1)
 
     def step():

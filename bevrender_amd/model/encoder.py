@@ -161,7 +161,9 @@ class BEVEncoder(nn.Module):
         `(b v) c h w` flatten + `img_backbone` (model/encoder.py:98-110)."""
         if img_tensor.dim() == 5:
             img_tensor = img_tensor.flatten(0, 1)                      # views into the batch
-        return self.img_backbone(img_tensor)
+        # channels-last staging (SURVEY 8f row 4): MIOpen's NHWC convolutions, and features that arrive in the layout
+        # the sampling kernel reads ((B*V, Hf, Wf, C) rows) -- ops.sample_features then takes them without a copy
+        return self.img_backbone(img_tensor.contiguous(memory_format=torch.channels_last))
 
     def history_features(self, img_tensor):
         """(B, T', V, 3, H, W) -> list of T' feature tensors (B*V, C, Hf, Wf), all frames through the backbone as ONE
@@ -170,7 +172,7 @@ class BEVEncoder(nn.Module):
         frames are independent and one launch set serves them all."""
         B, Tn, V = img_tensor.shape[:3]
         x = img_tensor.permute(1, 0, 2, 3, 4, 5).reshape(Tn * B * V, *img_tensor.shape[3:])   # frame-major
-        feat = self.img_backbone(x)
+        feat = self.img_backbone(x.contiguous(memory_format=torch.channels_last))
         return list(feat.reshape(Tn, B * V, *feat.shape[1:]).unbind(0))
 
     def forward(self, bev_query, img_tensor, prev_bev, vehicle_pose, vehicle_type_idx, wandb_log_dict,

@@ -478,3 +478,17 @@ def test_pack_kv_equals_the_stock_op_chain_and_unpack_is_its_adjoint(shape, prec
     assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, Bp, N, Np + 1, h, c, prec, p(Kr), p(Vr), None, None, st) == -2
     assert L.bevr_pack_kv(None, p(kv), 2 * Cc, Bp, N, Np, h, c, prec, p(Kr), p(Vr), None, None, st) == -1
     assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, Bp, N, Np, h, c, 5, p(Kr), p(Vr), None, None, st) == -3
+
+
+@pytest.mark.gpu
+def test_sample_features_takes_channels_last_features_without_a_copy():
+    """Backbone features staged channels-last (model/encoder.py backbone_features) are already the (B, Hi, Wi, C) rows
+    the sampling kernel reads: same result as from an NCHW tensor, and the layout change is a view."""
+    B, Cc, Hi, Wi, N = 2, 16, 6, 10, 50
+    g = torch.Generator().manual_seed(9)
+    feat = torch.randn(B, Cc, Hi, Wi, generator=g).to(DEV)
+    pos = (torch.rand(B, N, 2, generator=g) * 2.4 - 1.2).to(DEV)
+    cl = feat.contiguous(memory_format=torch.channels_last)
+    f = cl.reshape(B, 1, Cc, Hi, Wi).permute(0, 1, 3, 4, 2).reshape(B, Hi, Wi, Cc)
+    assert f.is_contiguous() and f.data_ptr() == cl.data_ptr()
+    assert torch.equal(ops.sample_features(cl, pos, 1), ops.sample_features(feat, pos, 1))

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
 #pragma unroll
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   float m = 0.f, l = 0.f;   // running max (log2 units) and denominator; the first tile sets m
+  float smax = -3.0e38f;    // F32 mode only: the largest logit seen (absolute), for LSE plane 1
 
   // ---- staging: global -> registers -> LDS ------------------------------------------------------
   constexpr int KCH_ROW = 32 * EB / 16;            // 16-B chunks per K row
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       float tm = s[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
+      if constexpr (PREC == BEVR_PREC_F32) smax = fmaxf(smax, tm + m);
       const bool first = (step == 0 && ks == 0);
       if (first || __any(tm > RESCALE_THR)) {   // wave-uniform: rare after the first tiles
         // the two lane halves hold the same queries (different keys): agree on the maximum only when it is needed
@@ -410,7 +412,16 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       for (int k = 0; k < 4; ++k) v[k] = o[4 * g4 + k] * inv;
       *reinterpret_cast<f32x4*>(orow + 8 * g4 + 4 * hi) = v;
     }
-    if (hi == 0) Lh[mq] = m + __log2f(lt);
+    const float lse = m + __log2f(lt);
+    const float smax_row = fmaxf(smax, __shfl_xor(smax, 32));   // the lane halves saw different keys
+    if (hi == 0) {
+      Lh[mq] = lse;
+      // plane 1: an upper bound of log2 of the row's largest softmax weight, for the backward's fixed-point scale.
+      // BF16 mode: every logit of the row is <= m + RESCALE_THR (a tile above that moves m), so P <= 2^THR / l -- free,
+      // where tracking the exact maximum costs a register and 7 % of the kernel at 128 VGPRs.  F32 mode (the parity
+      // mode, 212 VGPRs): the exact maximum.
+      Lh[(size_t)n_ph * Mp + mq] = PREC == BEVR_PREC_F32 ? smax_row - lse : RESCALE_THR - __log2f(lt);
+    }
   }
 }
 

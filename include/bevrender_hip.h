@@ -109,7 +109,10 @@ int bevr_attn_key_prep(const bevr_attn_desc* d, const float* key_a, const float*
  *       in-block index r is stored at position (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1)
  *       (bits 2 and 3 swapped) -- the order the MFMA consumes the P accumulator in.
  *   key_ws: output of bevr_attn_key_prep for these keys      table_pair as above, float
- *   O   [n_prob][heads][Mp][32] float (normalised)   LSE [n_prob][heads][Mp] float (log2 units) */
+ *   O   [n_prob][heads][Mp][32] float (normalised)
+ *   LSE [2][n_prob][heads][Mp] float: plane 0 the log2-sum-exp of the row (what the backward entry points read:
+ *       they take a pointer to plane 0), plane 1 an upper bound of log2 of the row's largest softmax weight (may exceed 0: clamp;
+ *       rows past the grid: unspecified), from which the caller may tighten grad_scale of bevr_attn_bwd_q */
 int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* Vt,
                   const void* key_ws, const float* table_pair,
                   float* O, float* LSE, void* stream);
@@ -120,7 +123,8 @@ int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const v
  *   V  [n_prob][heads][Np][32] E (row layout), Kt [like Vt] E, dO [n_prob][heads][Mp][32] E,
  *   delta [n_prob][heads][Mp] float = rowsum(dO * O).
  *   grad_scale [2] float (device): { s, 1/s } with s a power of two such that s * max|P (dP - delta)| <= 2^30; a
- *   valid bound is max_q |dO_q| * max_n |V_n| + max |delta| (Euclidean norms over the 32 channels; P <= 1).  The
+ *   valid bound is Pmax * (max_q |dO_q| * max_n |V_n| + max |delta|) (Euclidean norms over the 32 channels), Pmax = 1
+ *   or the largest softmax weight of the launch (2^max of LSE plane 1, with a margin for the recomputation).  The
  *   kernel multiplies dO and delta by s as it loads them (exact) and accumulates the table gradient in 64-bit fixed
  *   point with unit ln2 / s (each contribution rounded to nearest; sums are exact and order-independent within a
  *   workgroup's window, and a cell cannot wrap: 2^33 contributions of the largest size fit); ln2 / s is applied

@@ -155,7 +155,7 @@ def cfg2():
 # observed on MI355X (printed by the test, -s): see DESIGN.md section 3 for the table.
 # out: max |err| relative to max |want| over the subset; gradients: max |err| / max |want| per tensor.
 LIMITS = {
-    _lib.PREC_F32: dict(out=2e-4, query=5e-4, k=5e-4, v=5e-4, pos=1e-3, table=1e-3),
+    _lib.PREC_F32: dict(out=2e-4, query=5e-4, k=5e-4, v=5e-4, pos=1e-3, table=2.5e-4),
     _lib.PREC_BF16: dict(out=1.5e-2, query=3e-2, k=3e-2, v=2e-2, pos=4e-2, table=3e-2),
 }
 

@@ -41,7 +41,7 @@ __device__ __forceinline__ unsigned long long prof_now_f(float dep) {
 
 namespace {
 
-constexpr float RESCALE_THR = 8.0f;  // log2 units: lazy running-max update (P <= 2^8)
+constexpr float RESCALE_THR = 2.0f;  // log2 units: lazy running-max update (P <= 2^2); also the slack of LSE plane 1 in BF16 mode
 constexpr int TF = 512;              // threads per workgroup
 constexpr int NWF = TF / 64;         // waves = query columns per workgroup
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

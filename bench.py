@@ -32,6 +32,7 @@ import torch.nn as nn
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md chip-level parameters
 HBM_PEAK_GBS = 8000.0
+N_CU, CLOCK_HZ = 256, 2.4e9                          # for the LDS-pipe view (roofline_lds)
 
 
 def ring_rig(V, img_w, img_h):
@@ -335,6 +336,23 @@ def main():
                     "all_attention": {k: {"avg_ms": round(v["ms"] / v["n"], 3),
                                           "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 5)}
                                       for k, v in sorted(attn.items())}}
+        # What actually paces the attention kernels is per-pair work on the LDS pipe (bias taps, per-key constants, the
+        # table-gradient atomics), not the matrix cores.  Secondary, clearly separate from
+        # `roofline`: the pair rate against the rate at which one CU's LDS pipe could issue each kernel's LDS
+        # instructions back to back (clk per wave and key row = per 64 pairs, from the measured instruction costs in
+        # profiles/r02_lds_*.txt; bf16 mode).
+        LDS_CLK_PER_KEYROW = {"bevr_attn_fwd": 10.0,     # taps 4.8 + constants (b64 + b32 broadcast) 5.2
+                              "bevr_attn_bwd_q": 22.6,   # + two ds_add_u64 12.6
+                              "bevr_attn_bwd_k": 6.0}    # per-lane tap gathers: 3 reads per 4 rows and table column
+        roof_lds = []
+        if args.precision == "bf16":
+            n_mm = {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4}
+            for k, v in sorted(attn.items()):
+                prs = v["flops"] / (2.0 * 32 * n_mm[k]) / (v["ms"] * 1e-3)
+                peak_prs = N_CU * CLOCK_HZ * 64.0 / LDS_CLK_PER_KEYROW[k]
+                roof_lds.append({"bound": "lds", "kernel": k, "achieved": round(prs, 0), "peak": round(peak_prs, 0),
+                                 "unit": "pairs/s", "frac": round(prs / peak_prs, 4),
+                                 "lds_clk_per_wave_keyrow": LDS_CLK_PER_KEYROW[k]})
         # the HBM-bound kernels of the path: bilinear feature sampling, forward and backward scatter.
         # achieved = algorithmic (compulsory) bytes / launch time: feature map once + one row and one position per key
         # (forward); + the map's gradient once (backward).  `traffic` = what the PMC counters saw (the backward's
@@ -359,7 +377,7 @@ def main():
                                    f"+ 1 fwd+bwd), correlation head with contrastive + lifted-structure losses, AdamW; "
                                    f"batch {B} per GPU; backbone/render CNN excluded",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
-            "roofline": roof, "roofline_hbm": roof_hbm,
+            "roofline": roof, "roofline_hbm": roof_hbm, "roofline_lds": roof_lds,
         }
         if world == 1 and args.f32_steps > 0 and args.precision == "bf16":
             # the reference's arithmetic is fp32: the same workload in the kernels' exact-f32 MFMA mode, as a secondary

@@ -288,8 +288,11 @@ class _AttnCore(torch.autograd.Function):
         L = _lib.lib()
         ed = _edtype(geom.precision)
         dO = dO.contiguous()
-        delta = (dO * O).sum(-1).contiguous()
         dOe = dO.to(ed).contiguous()
+        # delta = rowsum(dO o O) from the SAME (rounded) dO the kernels contract with V for dP: dS = P (dP - delta) then
+        # cancels as it must where P -> 1 (with the f32 dO here and the bf16 one there, |dS| kept a floor of
+        # 2^-9 |dO||V| -- pure noise in dQ, dK, d(pos), d(table) of a row dominated by one key)
+        delta = (dOe.float() * O).sum(-1).contiguous()
         dev = dO.device
         d = geom.desc()
         # zeros: bwd_q walks the grid in 31-row tiles and never visits the padded rows S..Sp-1 of a column

@@ -1,0 +1,78 @@
+"""Seeded random sweep of the attention entry points against the CPU oracle: ragged BEV sizes, key counts around the
+64-key step and 384-key block boundaries, every supported head width, groups, several views, tables from narrow
+to wider than any LDS region, key positions inside / outside / clustered -- forward and every gradient, both
+precision modes.  Small cases (each well under a second on the GPU, a few seconds of oracle)."""
+import numpy as np
+import pytest
+import torch
+
+from bevrender_amd import _lib, ops
+from test_gpu_ops import _oracle_core, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def draw(seed):
+    r = np.random.RandomState(seed)
+    h = int(r.choice([1, 2, 4]))
+    c = int(r.choice([8, 16, 32]))
+    g = int(r.choice([d for d in (1, 2) if h % d == 0]))
+    V = int(r.choice([1, 1, 2, 3]))
+    B = int(r.choice([1, 2]))
+    S = int(r.choice([3, 5, 8, 13, 21, 31, 32, 33, 40]))
+    D = int(r.choice([1, 2, 3, 5, 9]))
+    N = int(r.choice([1, 7, 31, 32, 33, 63, 64, 65, 127, 200, 383, 384, 385, 450]))
+    mode = int(r.choice([0, 1, 2, 3]))
+    return B, V, h * c, h, g, S, D, N, mode
+
+
+def make(cfg, seed):
+    B, V, C, h, g, S, D, N, mode = cfg
+    gen = torch.Generator().manual_seed(seed)
+    query = torch.randn(B, C, S, S, generator=gen)
+    k = torch.randn(B * V, N, C, generator=gen)
+    v = torch.randn(B * V, N, C, generator=gen)
+    u = torch.rand(B * V * g, N, 2, generator=gen)
+    if mode == 0:      # inside the grid
+        pos = u * 2 - 1
+    elif mode == 1:    # well outside too (clamped taps, zero bias)
+        pos = (u * 2 - 1) * 1.6
+    elif mode == 2:    # one tight cluster: every key in the same few table cells (pinned-key case)
+        pos = -0.97 + 0.02 * u
+    else:              # two distant clusters inside one step
+        pos = torch.where(torch.arange(N)[None, :, None] % 2 == 0, -0.8 + 0.05 * u, 0.7 + 0.05 * u)
+    table = torch.randn(h, 2 * S - 1, 2 * S * D - 1, generator=gen) * 0.3
+    return query, k, v, pos, table
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_configuration(seed):
+    cfg = draw(seed)
+    B, V, C, h, g, S, D, N, mode = cfg
+    query, k, v, pos, table = make(cfg, 1000 + seed)
+    ins_cpu = [t.clone().requires_grad_(True) for t in (query, k, v, pos, table)]
+    want = _oracle_core(*ins_cpu, h, g, V)
+    cot = torch.randn(want.shape, generator=torch.Generator().manual_seed(seed))
+    want.backward(cot)
+    for prec, lim_o, lim_g in ((_lib.PREC_F32, 2e-4, 5e-4), (_lib.PREC_BF16, 2.5e-2, 3e-2)):
+        ins = [t.clone().to(DEV).requires_grad_(True) for t in (query, k, v, pos, table)]
+        got = ops.attention_core(*ins, heads=h, groups=g, views=V, precision=prec)
+        got.backward(cot.to(DEV))
+        torch.cuda.synchronize()
+        e = rel_err(got.detach().cpu(), want.detach())
+        assert e < lim_o, f"cfg {cfg} prec {prec}: out {e:.3e}"
+        for n, a, b in zip(("query", "k", "v", "pos", "table"), ins, ins_cpu):
+            if N == 1 and n in ("query", "pos", "table"):
+                # one key: P = 1 and dS = P (dP - delta) = 0 analytically.  What the kernels return is the rounding of
+                # dP against delta -- in BF16 mode dO enters dP rounded to bf16 and delta in f32, so |dS| ~ 2^-9 |dO||V|
+                lim0 = 5e-4 if prec == _lib.PREC_F32 else 5e-2
+                assert a.grad.abs().max().item() < lim0 and b.grad.abs().max().item() < 1e-5, (cfg, prec, n)
+                continue
+            if n == "pos":   # kinks of the piecewise-bilinear bias: compare in the 2-norm
+                e = ((a.grad.cpu() - b.grad).norm() / max(b.grad.norm().item(), 2e-2 * b.grad.numel() ** 0.5)).item()
+                assert e < (5e-3 if prec == _lib.PREC_F32 else 6e-2), f"cfg {cfg} prec {prec}: grad pos 2-norm {e:.3e}"
+                continue
+            # a gradient that is analytically ~0 (one key: P = 1, dS = 0) is rounding noise of O(1) terms: floor the scale
+            e = (a.grad.cpu() - b.grad).abs().max().item() / max(b.grad.abs().max().item(), 2e-2)
+            assert e < lim_g, f"cfg {cfg} prec {prec}: grad {n} {e:.3e}"

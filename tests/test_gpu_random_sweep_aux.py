@@ -1,0 +1,102 @@
+"""Seeded random sweeps of the other entry points against the stock PyTorch ops they replace (float64 on the CPU):
+feature sampling (F.grid_sample), depthwise convolution (F.conv2d, groups = C), the ego-motion warp (oracle.tv_affine
+twice) and the operand packing.  Small cases; BEVR_SWEEP=n widens them."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bevrender_amd import ops
+from oracle import bevrender_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NSEED = int(os.environ.get("BEVR_SWEEP", "24"))
+
+
+def rel(got, want, floor=1e-3):
+    return (got.double().cpu() - want.double()).abs().max().item() / max(want.abs().max().item(), floor)
+
+
+@pytest.mark.parametrize("seed", list(range(NSEED)))
+def test_sample_features_random(seed):
+    r = np.random.RandomState(seed)
+    g = int(r.choice([1, 1, 2, 4]))
+    C = 4 * g * int(r.choice([1, 2, 3, 8, 16]))
+    B = int(r.choice([1, 2, 5]))
+    Hi, Wi = int(r.randint(2, 40)), int(r.randint(2, 70))
+    N = int(r.choice([1, 3, 64, 257, 1000, 3001]))
+    gen = torch.Generator().manual_seed(seed)
+    feat = torch.randn(B, C, Hi, Wi, generator=gen)
+    pos = (torch.rand(B * g, N, 2, generator=gen) * 2 - 1) * float(r.choice([0.9, 1.0, 1.3]))
+    share = int(r.choice([0, 0, N // 2]))
+    pos[:, :share] = -1.0                                    # the projector's pin: pixel (0, 0)
+    if N > 3:
+        pos[0, -1] = torch.tensor([1.0, 1.0])                # the last pixel exactly
+        pos[0, -2] = torch.tensor([-1.0, 1.0])
+    cot = torch.randn(B, N, C, generator=gen)
+    fr, pr = feat.double().requires_grad_(True), pos.double().requires_grad_(True)
+    # reference: model/SCA_deform_attn.py:290-301 -- group gi's channels sampled at group gi's positions, grid in (x, y)
+    want = F.grid_sample(fr.reshape(B * g, C // g, Hi, Wi), pr[:, None, :, [1, 0]], mode="bilinear",
+                         padding_mode="zeros", align_corners=True)           # (B g, C/g, 1, N)
+    want = want.reshape(B, g, C // g, N).permute(0, 3, 1, 2).reshape(B, N, C)
+    want.backward(cot.double())
+    fg, pg = feat.clone().to(DEV).requires_grad_(True), pos.clone().to(DEV).requires_grad_(True)
+    got = ops.sample_features(fg, pg, g)
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(got.detach(), want.detach()) < 1e-5
+    assert rel(fg.grad, fr.grad) < 1e-5
+    # d(pos) is discontinuous where a coordinate sits exactly on a pixel centre (the pins, the corners): skip those keys
+    px = (pos[..., 1] + 1) * (Wi - 1) / 2
+    py = (pos[..., 0] + 1) * (Hi - 1) / 2
+    smooth = ((px - px.round()).abs() > 1e-4) & ((py - py.round()).abs() > 1e-4)
+    if smooth.any():
+        assert rel(pg.grad.cpu()[smooth], pr.grad[smooth]) < 1e-4
+
+
+@pytest.mark.parametrize("seed", list(range(NSEED)))
+def test_depthwise_conv_random(seed):
+    r = np.random.RandomState(100 + seed)
+    B, Cc = int(r.choice([1, 2, 3])), int(r.choice([1, 3, 4, 8, 20, 64, 256]))
+    H, W, k = int(r.randint(1, 30)), int(r.randint(1, 45)), int(r.choice([1, 3, 3, 5]))
+    nhwc = bool(r.randint(0, 2))
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cc, H, W, generator=gen)
+    w = torch.randn(Cc, 1, k, k, generator=gen) * 0.3
+    b = torch.randn(Cc, generator=gen) if r.randint(0, 2) else None
+    cot = torch.randn(B, Cc, H, W, generator=gen)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if b is not None else None
+    want = F.conv2d(xr, wr, br, padding=k // 2, groups=Cc)
+    want.backward(cot.double())
+    xg, wg = x.clone().to(DEV).requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
+    bg = b.clone().to(DEV).requires_grad_(True) if b is not None else None
+    if nhwc:
+        got = ops.depthwise_conv(xg.permute(0, 2, 3, 1).contiguous(), wg, bg, nhwc=True).permute(0, 3, 1, 2)
+    else:
+        got = ops.depthwise_conv(xg, wg, bg, nhwc=False)
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(got.detach(), want.detach()) < 1e-5
+    assert rel(xg.grad, xr.grad) < 1e-5
+    assert rel(wg.grad, wr.grad, floor=1e-2) < 2e-4
+    if b is not None:
+        assert rel(bg.grad, br.grad, floor=1e-2) < 2e-4
+
+
+@pytest.mark.parametrize("seed", list(range(max(NSEED // 2, 8))))
+def test_history_warp_random(seed):
+    r = np.random.RandomState(200 + seed)
+    B, Cc, S = int(r.choice([1, 2, 3])), int(r.choice([1, 4, 7, 16])), int(r.choice([4, 7, 14, 28, 33]))
+    gen = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, Cc, S, S, generator=gen)
+    ang = (torch.rand(B, generator=gen) - 0.5) * float(r.choice([0.0, 20.0, 170.0]))       # degrees
+    tr = (torch.rand(B, 2, generator=gen) - 0.5) * float(r.choice([0.0, 3.0, 2.0 * S]))    # pixels
+    want = torch.stack([O.tv_affine(img[i].double(), float(ang[i]), (float(tr[i, 0]), float(tr[i, 1])), 0.0)
+                        for i in range(B)], 0)
+    got = ops.affine_warp(img.to(DEV), torch.deg2rad(ang).to(DEV), tr.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(got, want) < 1e-4

@@ -1,7 +1,7 @@
 """Seeded random sweep of the TSA / SCA modules (offset heads, sampling, K|V projection and packing, attention,
 output projection -- the whole drop-in forward and its autograd) against the oracle's restatement of the reference
 modules, with the module's own randomly initialised state_dict: random BEV sizes, widths, heads, groups, strides,
-kernel sizes, depth bins, views, feature-map sizes.  F32 mode (the parity mode); BEVR_SWEEP=n widens it."""
+kernel sizes, depth bins, views, feature-map sizes.  Both precision modes; BEVR_SWEEP=n widens it."""
 import os
 
 import numpy as np
@@ -13,7 +13,7 @@ from oracle import bevrender_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-NSEED = int(os.environ.get("BEVR_SWEEP", "16"))
+NSEED = int(os.environ.get("BEVR_SWEEP", "12"))
 
 
 def randomize_(m, seed):
@@ -24,10 +24,10 @@ def randomize_(m, seed):
             p.copy_((torch.randn(p.shape, generator=g) * scale + (1.0 if n.endswith("norm.weight") or ".1.norm.weight" in n else 0.0)).to(p.device))
 
 
-def compare(m, out, want, ins_gpu, ins_cpu, params_cpu, tag, loose=False):
+def compare(m, out, want, ins_gpu, ins_cpu, params_cpu, tag, loose=False, bf16=False):
     def rel(a, b, floor=1e-3):
         return (a.double().cpu() - b.double()).abs().max().item() / max(b.abs().max().item(), floor)
-    assert rel(out.detach(), want.detach()) < 3e-4, f"{tag}: out {rel(out.detach(), want.detach()):.3e}"
+    assert rel(out.detach(), want.detach()) < (3e-2 if bf16 else 3e-4), f"{tag}: out {rel(out.detach(), want.detach()):.3e}"
     cot = torch.randn(want.shape, generator=torch.Generator().manual_seed(5)).double()
     want.backward(cot)
     out.backward(cot.float().to(DEV))
@@ -37,22 +37,26 @@ def compare(m, out, want, ins_gpu, ins_cpu, params_cpu, tag, loose=False):
         if b is None or b.grad is None:
             continue
         # (a case whose keys all fall outside the image has identical keys and analytically zero input gradients)
-        e = rel(a.grad, b.grad, floor=max(1e-2 * gmax, 1e-4))
-        assert e < (1e-2 if loose else 4e-3), f"{tag}: grad {name} {e:.3e}"   # offsets clamp / tanh-saturate: kinks in d(query) too
+        e = rel(a.grad, b.grad, floor=max(1e-2 * gmax, 2e-2 if bf16 else 1e-4))
+        assert e < (6e-2 if bf16 else 1e-2 if loose else 4e-3), f"{tag}: grad {name} {e:.3e}"   # offsets clamp / tanh-saturate: kinks in d(query) too
     pmax = max(v.grad.abs().max().item() for v in params_cpu.values() if v.grad is not None)
     for n, p in m.named_parameters():
         b = params_cpu[n]
         if b.grad is None:
             assert p.grad is None or p.grad.abs().max().item() == 0.0, f"{tag}: {n} has a gradient, the reference none"
             continue
-        e = rel(p.grad, b.grad, floor=max(2e-2 * pmax, 1e-4))
+        if n == "proj_k.bias":   # a constant added to every key moves no softmax: analytically zero, numerically noise
+            assert p.grad.abs().max().item() <= 0.1 * pmax + 1e-3, f"{tag}: {n}"
+            continue
+        e = rel(p.grad, b.grad, floor=max(2e-2 * pmax, 1e-2 if bf16 else 1e-4))
         # loose: without the tanh range the random offsets throw most keys onto the clamp at +-1 (pixel centres and the
         # table's edge: derivative jumps), and a few keys on the other side of one move the offset head's gradients
-        assert e < (1e-2 if loose else 3e-3), f"{tag}: grad {n} {e:.3e}"
+        assert e < (6e-2 if bf16 else 1e-2 if loose else 3e-3), f"{tag}: grad {n} {e:.3e}"
 
 
+@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16])
 @pytest.mark.parametrize("seed", list(range(NSEED)))
-def test_tsa_module_random(seed):
+def test_tsa_module_random(seed, prec):
     from bevrender_amd.model.TSA_deform_attn import TSADeformableAttention
     r = np.random.RandomState(seed)
     h = int(r.choice([1, 2, 4]))
@@ -65,7 +69,7 @@ def test_tsa_module_random(seed):
     xnone = bool(r.randint(0, 3) == 0)
     sor = bool(r.randint(0, 4) != 0)
     m = TSADeformableAttention(bev_feat_shape=S, dim_embed=C, n_heads=h, n_groups=1, stride=s, kernel_size=k,
-                               scale_offset_range=sor, batch_size=B, n_views=1, precision=_lib.PREC_F32).to(DEV)
+                               scale_offset_range=sor, batch_size=B, n_views=1, precision=prec).to(DEV)
     randomize_(m, 100 + seed)
     g = torch.Generator().manual_seed(seed)
     query = torch.randn(B, C, S, S, generator=g)
@@ -77,11 +81,12 @@ def test_tsa_module_random(seed):
     qg = query.clone().to(DEV).requires_grad_(True)
     xg = None if prev is None else prev.clone().to(DEV).requires_grad_(True)
     out, _ = m(xg, qg, None, False)
-    compare(m, out, want, (qg, xg), (qc, xc), p_cpu, f"tsa seed {seed} C{C} h{h} S{S} k{k}s{s} xnone{xnone} sor{sor}", loose=not sor)
+    compare(m, out, want, (qg, xg), (qc, xc), p_cpu, f"tsa seed {seed} C{C} h{h} S{S} k{k}s{s} xnone{xnone} sor{sor} prec{prec}", loose=not sor, bf16=prec == _lib.PREC_BF16)
 
 
+@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16])
 @pytest.mark.parametrize("seed", list(range(NSEED)))
-def test_sca_module_random(seed):
+def test_sca_module_random(seed, prec):
     from bevrender_amd.model.SCA_deform_attn import SCADeformableAttention
     r = np.random.RandomState(500 + seed)
     h = int(r.choice([2, 4]))
@@ -95,7 +100,7 @@ def test_sca_module_random(seed):
     sor = bool(r.randint(0, 4) != 0)
     m = SCADeformableAttention(bev_feat_shape=S, bev_depth_dim=D, dim_embed=C, n_heads=h, n_groups=g, stride=1,
                                kernel_size=3, scale_offset_range=sor, batch_size=B, n_views=V,
-                               precision=_lib.PREC_F32).to(DEV)
+                               precision=prec).to(DEV)
     randomize_(m, 900 + seed)
     gen = torch.Generator().manual_seed(seed)
     query = torch.randn(B, C, S, S, generator=gen)
@@ -107,4 +112,4 @@ def test_sca_module_random(seed):
     want = O.sca_forward(p_cpu, xc, qc, ref.double(), n_heads=h, n_groups=g, depth_dim=D, scale_offset_range=sor)
     qg, xg = query.clone().to(DEV).requires_grad_(True), x.clone().to(DEV).requires_grad_(True)
     out, _ = m(xg, qg, ref.to(DEV), None, False)
-    compare(m, out, want, (qg, xg), (qc, xc), p_cpu, f"sca seed {seed} C{C} h{h} g{g} S{S} D{D} V{V} {Hi}x{Wi} sor{sor}", loose=not sor)
+    compare(m, out, want, (qg, xg), (qc, xc), p_cpu, f"sca seed {seed} C{C} h{h} g{g} S{S} D{D} V{V} {Hi}x{Wi} sor{sor} prec{prec}", loose=not sor, bf16=prec == _lib.PREC_BF16)

@@ -113,3 +113,66 @@ def test_sca_module_random(seed, prec):
     qg, xg = query.clone().to(DEV).requires_grad_(True), x.clone().to(DEV).requires_grad_(True)
     out, _ = m(xg, qg, ref.to(DEV), None, False)
     compare(m, out, want, (qg, xg), (qc, xc), p_cpu, f"sca seed {seed} C{C} h{h} g{g} S{S} D{D} V{V} {Hi}x{Wi} sor{sor} prec{prec}", loose=not sor, bf16=prec == _lib.PREC_BF16)
+
+
+@pytest.mark.parametrize("seed", list(range(max(NSEED // 2, 6))))
+def test_encoder_layer_random(seed):
+    """One EncoderLayer (LPU depthwise, shared LayerNorm, TSA, conv-MLP, LPU, SCA over a random camera ring with the
+    projected pillar grid, conv-MLP), train mode, F32: forward, input and every parameter gradient against the oracle's
+    layer restatement with the layer's own random state_dict."""
+    from bevrender_amd.model.bev_cmr_proj import BEV2CameraProjector
+    from bevrender_amd.model.encoder import EncoderLayer
+    from test_gpu_fullsize import ring_rig
+    r = np.random.RandomState(700 + seed)
+    h = int(r.choice([2, 4]))
+    C = h * int(r.choice([8, 16]))
+    S = int(r.choice([6, 8, 12, 14]))
+    D = int(r.choice([2, 3, 5]))
+    V = int(r.choice([1, 2, 3]))
+    B = int(r.choice([1, 2]))
+    img_w, img_h = 64 * int(r.choice([1, 2])), 32 * int(r.choice([1, 2]))
+    Hi, Wi = img_h // 4, img_w // 4
+    bound = {"X": float(r.choice([10, 20, 50])), "Y": float(r.choice([10, 20, 50])), "Z": 2.0}
+    T, K = ring_rig(V, img_w, img_h)
+    proj = BEV2CameraProjector(imu_to_rgb={0: [t.copy() for t in T]}, K={0: [k.copy() for k in K]},
+                               vehicle_type_code=0, img_width=img_w, img_height=img_h, ori_img_width=img_w,
+                               ori_img_height=img_h, device=DEV)
+    layer = EncoderLayer(bev_bound=bound, bev2cmr_projector=proj, n_views=V, bev_feat_shape=S, bev_depth_dim=D,
+                         z_shift=-1.0, dim_embed=C, expansion=4, stage_idx=0, n_groups=1, n_heads=h, stride=1,
+                         kernel_size=3, batch_size=B, scale_offset_range=True, drop_path_rate=0.0,
+                         precision=_lib.PREC_F32).to(DEV)
+    randomize_(layer, 1300 + seed)
+    layer.train()
+    gen = torch.Generator().manual_seed(seed)
+    bev = torch.randn(B, C, S, S, generator=gen)
+    prev = torch.randn(B, C, S, S, generator=gen)
+    feat = torch.randn(B * V, C, Hi, Wi, generator=gen)
+    p_cpu = {n: v.detach().cpu().double().requires_grad_(True) for n, v in layer.state_dict().items()
+             if v.dtype.is_floating_point}
+    pts = O.sample_3d_points(bound, S, D, -1.0)
+    ref = O.sca_reference_points(O.bev_grid_to_camera(pts, T, K, img_w, img_h, img_w, img_h), B).double()
+    bc, pc, fc = (t.double().requires_grad_(True) for t in (bev, prev, feat))
+    want = O.encoder_layer_forward(p_cpu, bc, fc, pc, ref, n_heads=h, n_groups=1, depth_dim=D, n_views=V, kernel_size=3,
+                                   stride=1, scale_offset_range=True)
+    bg, pg, fg = (t.clone().to(DEV).requires_grad_(True) for t in (bev, prev, feat))
+    out, _ = layer(bg, fg, pg, torch.zeros(B, 2, 3, device=DEV), torch.tensor(0), {}, False)
+    tag = f"layer seed {seed} C{C} h{h} S{S} D{D} V{V} B{B} {img_w}x{img_h}"
+    rel = lambda a, b, floor: (a.double().cpu() - b.double()).abs().max().item() / max(b.abs().max().item(), floor)
+    assert rel(out.detach(), want.detach(), 1e-3) < 5e-4, f"{tag}: out"
+    cot = torch.randn(want.shape, generator=torch.Generator().manual_seed(5)).double()
+    want.backward(cot)
+    out.backward(cot.float().to(DEV))
+    torch.cuda.synchronize()
+    for name, a, b in (("bev_query", bg, bc), ("prev_bev", pg, pc), ("img_feat", fg, fc)):
+        e = rel(a.grad, b.grad, 1e-3)
+        assert e < 5e-3, f"{tag}: grad {name} {e:.3e}"
+    pmax = max(v.grad.abs().max().item() for v in p_cpu.values() if v.grad is not None)
+    for n, p in layer.named_parameters():
+        b = p_cpu[n]
+        if b.grad is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, f"{tag}: {n} has a gradient, the reference none"
+            continue
+        if n.endswith("proj_k.bias"):
+            continue
+        e = rel(p.grad, b.grad, max(2e-2 * pmax, 1e-4))
+        assert e < 5e-3, f"{tag}: grad {n} {e:.3e}"

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   float acc = 0.f;
   for (int k = threadIdx.x * 4; k < ECHUNK; k += 1024) {
     long long e = e0 + k;
-    if (e + 3 < E) {
+    if ((E & 3) == 0 && e + 3 < E) {   // rows are 16-byte aligned only when E % 4 == 0
       f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * E + e);
       acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     } else {
@@ -165,12 +165,8 @@ extern "C" int bevr_corr_fwd(const float* cam, const float* map, float* D, float
   if (normalize) {
     if ((e = hipMemsetAsync(inv_norm_cam, 0, n * sizeof(float), st)) != hipSuccess) return (int)e;
     if ((e = hipMemsetAsync(inv_norm_map, 0, m * sizeof(float), st)) != hipSuccess) return (int)e;
-    if ((E & 3) == 0) {
-      hipLaunchKernelGGL(rownorm_kernel, dim3(chunks, n), dim3(256), 0, st, cam, inv_norm_cam, n, E);
-      hipLaunchKernelGGL(rownorm_kernel, dim3(chunks, m), dim3(256), 0, st, map, inv_norm_map, m, E);
-    } else {
-      return BEVR_E_SHAPE;  // normalised path requires E % 4 == 0 (true for C*S*S embeddings)
-    }
+    hipLaunchKernelGGL(rownorm_kernel, dim3(chunks, n), dim3(256), 0, st, cam, inv_norm_cam, n, E);
+    hipLaunchKernelGGL(rownorm_kernel, dim3(chunks, m), dim3(256), 0, st, map, inv_norm_map, m, E);
     hipLaunchKernelGGL(finish_norm_kernel, dim3((n + 63) / 64), dim3(64), 0, st, inv_norm_cam, n);
     hipLaunchKernelGGL(finish_norm_kernel, dim3((m + 63) / 64), dim3(64), 0, st, inv_norm_map, m);
   }

@@ -1,6 +1,7 @@
 """Seeded random sweeps of the other entry points against the stock PyTorch ops they replace (float64 on the CPU):
 feature sampling (F.grid_sample), depthwise convolution (F.conv2d, groups = C), the ego-motion warp (oracle.tv_affine
-twice) and the operand packing.  Small cases; BEVR_SWEEP=n widens them."""
+twice) and the correlation head (pairwise correlation, margin losses, recall) against the oracle.  Small cases;
+BEVR_SWEEP=n widens them."""
 import os
 
 import numpy as np
@@ -100,3 +101,53 @@ def test_history_warp_random(seed):
     got = ops.affine_warp(img.to(DEV), torch.deg2rad(ang).to(DEV), tr.to(DEV))
     torch.cuda.synchronize()
     assert rel(got, want) < 1e-4
+
+
+@pytest.mark.parametrize("seed", list(range(max(NSEED // 2, 8))))
+def test_retrieval_losses_and_corr_random(seed):
+    """The correlation head at random batch sizes, embedding widths and noise levels: pairwise correlation (both
+    normalisations) and the three margin losses, values and both gradients, against the oracle; recall against the
+    oracle's NumPy form."""
+    from bevrender_amd.loss.contrastive_loss import ContrastiveLoss
+    from bevrender_amd.loss.lift_loss import LiftedStructureLoss
+    from bevrender_amd.loss.triplet_loss_metric import TripletLossMetricLearning
+    from bevrender_amd.retrieval import get_recall
+    r = np.random.RandomState(300 + seed)
+    B = int(r.choice([2, 3, 5, 8, 13, 16, 32]))
+    E = int(r.choice([3, 7, 64, 1000, 4097, 50176]))   # (E = 1: a normalised scalar has no gradient at all)
+    noise = float(r.choice([0.1, 1.0, 5.0, 30.0]))
+    gen = torch.Generator().manual_seed(seed)
+    cam = torch.randn(B, E, generator=gen)
+    mp = cam + noise * torch.linspace(0.2, 1.5, B)[:, None] * torch.randn(B, E, generator=gen)
+    for normalize in (False, True):
+        cc, mc = cam.double().requires_grad_(True), mp.double().requires_grad_(True)
+        a, b = (F.normalize(cc, dim=1), F.normalize(mc, dim=1)) if normalize else (cc, mc)
+        want = O.pairwise_corr(a, b)
+        cot = torch.randn(B, B, generator=gen)
+        want.backward(cot.double())
+        cg, mg = cam.clone().to(DEV).requires_grad_(True), mp.clone().to(DEV).requires_grad_(True)
+        got = ops.pairwise_corr(cg, mg, normalize)
+        got.backward(cot.to(DEV))
+        torch.cuda.synchronize()
+        assert (got.detach().cpu().double() - want.detach()).abs().max().item() < 3e-5 * max(want.abs().max().item(), 1.0)
+        assert rel(cg.grad, cc.grad, floor=1e-6) < 2e-4 and rel(mg.grad, mc.grad, floor=1e-6) < 2e-4
+    for mod, fn in ((ContrastiveLoss(), O.contrastive_loss), (LiftedStructureLoss(), O.lifted_structure_loss),
+                    (TripletLossMetricLearning(), O.triplet_margin_loss)):
+        cc, mc = cam.double().requires_grad_(True), mp.double().requires_grad_(True)
+        want = fn(cc, mc)
+        want.backward()
+        cg, mg = cam.clone().to(DEV).requires_grad_(True), mp.clone().to(DEV).requires_grad_(True)
+        got = mod.get_loss(cg, mg)
+        got.backward()
+        torch.cuda.synchronize()
+        name = f"{type(mod).__name__} B{B} E{E} noise{noise}"
+        assert abs(got.item() - want.item()) < 5e-5 * max(1.0, abs(want.item())), f"{name}: {got.item()} vs {want.item()}"
+        for x, y in ((cg, cc), (mg, mc)):
+            gy = y.grad if y.grad is not None else torch.zeros_like(y)
+            gx = x.grad if x.grad is not None else torch.zeros_like(x)
+            assert rel(gx, gy, floor=1e-4 * max(gy.abs().max().item(), 1e-6) + 1e-9) < 2e-3 or \
+                (gx.double().cpu() - gy).abs().max().item() < 1e-7, name
+    cn, mn = F.normalize(cam, dim=1), F.normalize(mp, dim=1)
+    want = O.get_recall(cn.double().numpy(), mn.double().numpy())
+    got = get_recall(cn.to(DEV), mn.to(DEV), exact=True)
+    np.testing.assert_allclose(np.array(got), np.array(want), atol=1e-9)

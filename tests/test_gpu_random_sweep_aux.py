@@ -151,3 +151,42 @@ def test_retrieval_losses_and_corr_random(seed):
     want = O.get_recall(cn.double().numpy(), mn.double().numpy())
     got = get_recall(cn.to(DEV), mn.to(DEV), exact=True)
     np.testing.assert_allclose(np.array(got), np.array(want), atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", list(range(max(NSEED // 2, 8))))
+def test_projector_random_rig(seed):
+    """BEV pillar grid -> camera pixels (model/bev_cmr_proj.py:61-124) for random rigs: 1-6 cameras at random yaw, pitch,
+    roll, height and lateral offset, random focal lengths and principal points, image sizes and rescale ratios, BEV
+    bounds, S, D, z shift -- against the oracle, with the boundary-flip accounting of test_gpu_ops._check_projection."""
+    import math
+    from bevrender_amd.model.SCA import pillar_grid
+    from bevrender_amd.model.bev_cmr_proj import BEV2CameraProjector
+    from test_gpu_ops import _check_projection
+    r = np.random.RandomState(800 + seed)
+    V = int(r.randint(1, 7))
+    S, D = int(r.choice([4, 8, 14, 28, 50])), int(r.choice([1, 2, 3, 5]))
+    ow, oh = int(r.choice([128, 704, 1408])), int(r.choice([128, 256, 512]))
+    iw, ih = int(ow // r.choice([1, 2, 4])), int(oh // r.choice([1, 2]))
+    bound = {"X": float(r.choice([10, 20, 50])), "Y": float(r.choice([10, 50])), "Z": float(r.choice([2, 4]))}
+    zs = float(r.choice([-1.0, 0.0, 0.5]))
+    R0 = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=np.float64)
+    T, K = [], []
+    for v in range(V):
+        yaw, pitch, roll = r.uniform(-math.pi, math.pi), r.uniform(-0.3, 0.3), r.uniform(-0.1, 0.1)
+        cz, sz, cy, sy, cx, sx = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        M = np.eye(4)
+        M[:3, :3] = Rz @ Ry @ Rx @ R0
+        M[:3, 3] = (r.uniform(-1, 1), r.uniform(-1, 1), r.uniform(0.5, 3.0))
+        T.append(M)
+        f = r.uniform(0.4, 1.5) * ow
+        K.append(np.array([[f, 0, ow * r.uniform(0.4, 0.6), 0], [0, f * r.uniform(0.9, 1.1), oh * r.uniform(0.4, 0.6), 0],
+                           [0, 0, 1, 0]]))
+    proj = BEV2CameraProjector(imu_to_rgb={0: [t.copy() for t in T]}, K={0: [k.copy() for k in K]}, vehicle_type_code=0,
+                               img_width=iw, img_height=ih, ori_img_width=ow, ori_img_height=oh, device=DEV)
+    pts = pillar_grid(bound, S, D, zs)
+    got = torch.stack(proj.bev_grid_to_camera(pts)[0], 0).cpu().numpy()
+    want = torch.stack(O.bev_grid_to_camera(O.sample_3d_points(bound, S, D, zs), T, K, iw, ih, ow, oh), 0).numpy()
+    _check_projection(got, want, pts, T, K, iw, ih, ow, oh, f"rig seed {seed} V{V} S{S} D{D} {iw}x{ih}")

@@ -30,14 +30,20 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ 
                                                       E* __restrict__ Vt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   E* tile = reinterpret_cast<E*>(smem_raw);   // [kind 2][head][key 64][32]
+  // heads are processed HG at a time (blockIdx.z) so that the tile fits 64 KB of LDS for any head count
   const int b = blockIdx.y, n0 = blockIdx.x * PK, tid = threadIdx.x;
+  const int hg = (int)(32768 / (2 * PK * 32 * sizeof(E)));   // 4 heads of bf16, 2 of float
+  const int head0 = blockIdx.z * hg, all_heads = heads;
+  const float* koff = k + (size_t)head0 * c;
+  const float* voff = v + (size_t)head0 * c;
+  heads = min(hg, all_heads - head0);
   const int C = heads * c;
   const int n_el = 2 * heads * PK * 32;
   if (c < 32 || n0 + PK > N) {   // zero padding (channels c..31, keys past N)
     for (int i = tid; i < n_el; i += 256) tile[i] = to_elem<E>(0.f);
     __syncthreads();
   }
-  const float* src[2] = {k + (size_t)b * N * ld, v + (size_t)b * N * ld};
+  const float* src[2] = {koff + (size_t)b * N * ld, voff + (size_t)b * N * ld};
 #pragma unroll
   for (int kind = 0; kind < 2; ++kind) {
     for (int i = tid; i < PK * C; i += 256) {
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ 
   for (int i = tid; i < 2 * heads * PK * CPR; i += 256) {
     const int chunk = i % CPR, key = (i / CPR) % PK, hk = i / (CPR * PK);   // hk = kind * heads + head
     const int kind = hk / heads, head = hk - kind * heads;
-    E* dst = (kind ? Vr : Kr) + (((size_t)b * heads + head) * Np + n0 + key) * 32 + chunk * EPC;
+    E* dst = (kind ? Vr : Kr) + (((size_t)b * all_heads + head0 + head) * Np + n0 + key) * 32 + chunk * EPC;
     *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(tile + (hk * PK + key) * 32 + chunk * EPC);
   }
   // transposed layout: (head, channel) rows of Np keys; this tile's 64 keys are contiguous, permuted inside each 32
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ 
       const int keyp = (l & ~31) + perm32(l & 31);         // Xt[.., ch, l] = X[.., perm(l), ch]
       tmp[e] = tile[(hk * PK + keyp) * 32 + ch];
     }
-    E* dst = dbase + (((size_t)b * heads + head) * 32 + ch) * Np + n0 + chunk * EPC;
+    E* dst = dbase + (((size_t)b * all_heads + head0 + head) * 32 + ch) * Np + n0 + chunk * EPC;
     u32x4 w;
     __builtin_memcpy(&w, tmp, 16);
     *reinterpret_cast<u32x4*>(dst) = w;
@@ -105,10 +111,10 @@ extern "C" int bevr_pack_kv(const float* k, const float* v, long long ld, int n_
   if (precision != BEVR_PREC_BF16 && precision != BEVR_PREC_F32) return BEVR_E_PRECISION;
   if (!bevr_aligned16(Kr) || !bevr_aligned16(Vr) || (Kt && !bevr_aligned16(Kt)) || (Vt && !bevr_aligned16(Vt)))
     return BEVR_E_ALIGN;
-  const dim3 grid(Np / PK, n_prob);
   const size_t eb = precision == BEVR_PREC_BF16 ? 2 : 4;
-  const size_t lds = (size_t)2 * heads * PK * 32 * eb;
-  if (lds > 64 * 1024) return BEVR_E_SHAPE;
+  const int hg = (int)(32768 / (2 * PK * 32 * eb));
+  const dim3 grid(Np / PK, n_prob, (heads + hg - 1) / hg);
+  const size_t lds = (size_t)2 * (heads < hg ? heads : hg) * PK * 32 * eb;
   hipStream_t st = (hipStream_t)stream;
   if (precision == BEVR_PREC_BF16)
     hipLaunchKernelGGL(pack_kv_kernel<unsigned short>, grid, dim3(256), lds, st, k, v, ld, N, Np, heads, c,

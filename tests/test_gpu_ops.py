@@ -437,7 +437,7 @@ def test_depthwise_conv_matches_torch(shape, nhwc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16])
-@pytest.mark.parametrize("shape", [(3, 300, 2, 32), (2, 129, 2, 8), (1, 64, 4, 16)])
+@pytest.mark.parametrize("shape", [(3, 300, 2, 32), (2, 129, 2, 8), (1, 64, 4, 16), (2, 70, 16, 32), (1, 65, 5, 24)])
 def test_pack_kv_equals_the_stock_op_chain_and_unpack_is_its_adjoint(shape, prec):
     """csrc/pack.hip against the chain it replaces (ops.pack_keys -> dtype cast -> ops._perm_t): bit-identical in both
     element types, zero padding included; bevr_unpack_dkv returns exactly the rows the packing read."""

@@ -37,7 +37,7 @@ def compare(m, out, want, ins_gpu, ins_cpu, params_cpu, tag, loose=False, bf16=F
         if b is None or b.grad is None:
             continue
         # (a case whose keys all fall outside the image has identical keys and analytically zero input gradients)
-        e = rel(a.grad, b.grad, floor=max(1e-2 * gmax, 2e-2 if bf16 else 1e-4))
+        e = rel(a.grad, b.grad, floor=max(1e-2 * gmax, 1e-1 if bf16 else 1e-3))
         assert e < (6e-2 if bf16 else 1e-2 if loose else 4e-3), f"{tag}: grad {name} {e:.3e}"   # offsets clamp / tanh-saturate: kinks in d(query) too
     pmax = max(v.grad.abs().max().item() for v in params_cpu.values() if v.grad is not None)
     for n, p in m.named_parameters():

@@ -20,12 +20,13 @@ LIB_PATH = os.environ.get("BEVRENDER_LIB") or os.path.join(_HERE, "lib", "libbev
 CSRC = os.path.join(_HERE, "csrc")
 
 PREC_F32, PREC_BF16 = 0, 1
+ABI_VERSION = 3   # BEVR_ABI_VERSION of include/bevrender_hip.h this binding was written against
 
 # every symbol include/bevrender_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "bevr_abi_version", "bevr_strerror", "bevr_attn_table_dims", "bevr_attn_key_ws_bytes", "bevr_attn_key_prep",
     "bevr_attn_fwd", "bevr_attn_bwd_q",
-    "bevr_attn_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_project_bev_grid", "bevr_project_bev_grid_masked", "bevr_corr_fwd",
+    "bevr_attn_bwd_k", "bevr_attn_cell_fwd", "bevr_attn_cell_bwd_q", "bevr_attn_cell_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_project_bev_grid", "bevr_project_bev_grid_masked", "bevr_corr_fwd",
     "bevr_corr_bwd", "bevr_recall_rank", "bevr_dwconv_fwd", "bevr_dwconv_bwd_w", "bevr_affine_warp_fwd", "bevr_affine_warp_bwd",
     "bevr_offset_head_fwd", "bevr_offset_head_bwd", "bevr_pack_kv", "bevr_unpack_dkv",
 ]
@@ -82,6 +83,9 @@ def lib() -> C.CDLL:
         L.bevr_attn_fwd.argtypes = [dp, vp, vp, vp, vp, fp, fp, fp, vp]
         L.bevr_attn_bwd_q.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, fp, fp, fp, fp, fp, vp]
         L.bevr_attn_bwd_k.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, vp, fp, fp] + [fp] * 4 + [vp]
+        L.bevr_attn_cell_fwd.argtypes = [dp, vp, vp, vp, vp, fp, fp, fp, fp, fp, vp]
+        L.bevr_attn_cell_bwd_q.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, fp, fp, fp, fp, vp]
+        L.bevr_attn_cell_bwd_k.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, vp, fp, fp] + [fp] * 4 + [vp]
         L.bevr_sample_fwd.argtypes = [fp, fp, fp] + [ip] * 5 + [vp]
         L.bevr_sample_bwd.argtypes = [fp] * 5 + [ip] * 5 + [vp]
         L.bevr_project_bev_grid.argtypes = [fp] * 4 + [ip] * 4 + [vp]
@@ -95,16 +99,17 @@ def lib() -> C.CDLL:
         L.bevr_affine_warp_bwd.argtypes = [fp, fp, fp] + [ip] * 4 + [vp]
         L.bevr_offset_head_fwd.argtypes = [fp] * 7 + [C.c_longlong] + [ip] * 4 + [C.c_float, vp]
         L.bevr_offset_head_bwd.argtypes = [fp] * 13 + [C.c_longlong] + [ip] * 4 + [C.c_float, vp]
-        L.bevr_pack_kv.argtypes = [fp, fp, C.c_longlong] + [ip] * 6 + [vp] * 5
-        L.bevr_unpack_dkv.argtypes = [fp] * 4 + [C.c_longlong] + [ip] * 5 + [vp]
+        L.bevr_pack_kv.argtypes = [fp, fp, C.c_longlong, C.c_longlong] + [ip] * 6 + [vp] * 5
+        L.bevr_unpack_dkv.argtypes = [fp] * 4 + [C.c_longlong, C.c_longlong] + [ip] * 5 + [vp]
         for name in SYMBOLS:
             fn = getattr(L, name)
             if name == "bevr_attn_key_ws_bytes":
                 fn.restype = C.c_size_t
             elif name not in ("bevr_strerror",):
                 fn.restype = C.c_int
-        if L.bevr_abi_version() != 2:
-            raise BevrError("libbevrender_hip.so ABI version mismatch")
+        if L.bevr_abi_version() != ABI_VERSION:
+            raise BevrError(f"libbevrender_hip.so ABI version {L.bevr_abi_version()} != {ABI_VERSION}: rebuild "
+                            "(make -C bevrender_amd/csrc)")
         _lib = L
     return _lib
 

@@ -1,0 +1,442 @@
+// Attention backward, query side, over a CELL-SORTED key segment (attn_cell.h): dQ and the rpe-table gradient.
+// Counterpart of attn_bwd_q.hip for keys whose 32-key tiles fit one table chunk; same operand layouts, same gradient
+// semantics (include/bevrender_hip.h), same work split as attn_cell_fwd.hip (workgroup = one BEV column, waves = its
+// 32-row blocks).
+//
+// The table gradient of a tile is the transpose of its bias product:
+//   dTsh[k'][i] += sum_n W[n][k'] dS^T[n][i]          (k' = chunk cell, i = BEV row of the lane)
+// one MFMA pair with dS^T taken straight from the accumulator as the B operand (as dQ is), into 8 live accumulator
+// registers per lane that persist for as long as consecutive tiles share the chunk origin -- no per-pair LDS atomics,
+// no fixed point.  When the origin changes (3 % of the tiles of a cell-sorted segment) the wave adds its 16 cells x 32
+// rows to the table gradient in HBM with float atomics (32 consecutive rows of one table column per instruction and
+// lane half: two contiguous 128-byte runs).
+// Tiles that do not fit one chunk are left to a second, SLOW pass of the same kernel (per-pair gathers from the table in
+// global memory, float atomics; its workgroups exit at once when their column has no such tile).
+// dQ and dtable are ACCUMULATED: the region kernel (attn_bwd_q.hip) may have written the other key segment's share.
+#include "attn_cell.h"
+
+namespace {
+
+template <int PREC> struct LdsCQ {
+  static constexpr int EB = Elem<PREC>::bytes;
+  static constexpr int R_STRIDE = 32 * EB + 16;     // K, V rows
+  static constexpr int T_STRIDE = KT * EB + 16;     // K^T channel rows
+  static constexpr int R_BYTES = KT * R_STRIDE;
+  static constexpr int T_BYTES = 32 * T_STRIDE;
+  static constexpr int KW_BYTES = KT * 16;
+  static constexpr int WL = 8 * EB;                 // one lane's chunk operand (lane = key)
+  static constexpr int W_BYTES = 2 * 64 * WL;
+  static constexpr int WT_STRIDE = 32 * EB + 16;    // W^T rows: 32 key positions (perm32 order) per chunk cell
+  static constexpr int WT_TILE = 32 * WT_STRIDE;    // 32 rows: cells 16..31 stay zero (one chunk = 16 cells)
+  static constexpr int BUF = 2 * R_BYTES + T_BYTES + KW_BYTES + W_BYTES + 2 * WT_TILE;
+  static constexpr int RCH_ROW = 32 * EB / 16;
+  static constexpr int TCH_ROW = KT * EB / 16;
+  static constexpr int CH = KT * RCH_ROW;
+  static constexpr int NCH = 3 * CH + KT;
+  static constexpr int NST = PREC == BEVR_PREC_BF16 ? 2 : 4;
+  static constexpr int OFF_V = R_BYTES, OFF_KT = 2 * R_BYTES, OFF_KW = 2 * R_BYTES + T_BYTES, OFF_W = OFF_KW + KW_BYTES,
+                       OFF_WT = OFF_W + W_BYTES;
+};
+
+template <int PREC>
+__device__ __forceinline__ void chunk_map_q(int g, const char* Kh, const char* Vh, const char* Kth, const char* kws,
+                                            int Np, const char*& src, int& inc, int& dst) {
+  typedef LdsCQ<PREC> L;
+  constexpr int EB = L::EB;
+  if (g < 2 * L::CH) {
+    const int kind = g / L::CH, ci = g % L::CH;
+    src = (kind ? Vh : Kh) + (size_t)ci * 16;
+    inc = L::CH * 16;
+    dst = kind * L::R_BYTES + (ci / L::RCH_ROW) * L::R_STRIDE + (ci % L::RCH_ROW) * 16;
+  } else if (g < 3 * L::CH) {
+    const int ci = g - 2 * L::CH;
+    src = Kth + ((size_t)(ci / L::TCH_ROW) * Np) * EB + (ci % L::TCH_ROW) * 16;
+    inc = KT * EB;
+    dst = L::OFF_KT + (ci / L::TCH_ROW) * L::T_STRIDE + (ci % L::TCH_ROW) * 16;
+  } else {
+    const int ci = g - 3 * L::CH;
+    src = kws + (size_t)ci * 16;
+    inc = KT * 16;
+    dst = L::OFF_KW + ci * 16;
+  }
+}
+
+// acc1 += A1 * X, acc2 += A2 * X with X an accumulator-layout tile used as the B operand of both (bevr_common.h:
+// mma_acc_b), converted to bf16 once.
+__device__ __forceinline__ void mma_acc_b2(const Frag<BEVR_PREC_BF16>& a1, const Frag<BEVR_PREC_BF16>& a2, const f32x16& x,
+                                           f32x16& acc1, f32x16& acc2) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    u32x4 w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(x[8 * s + 2 * k], x[8 * s + 2 * k + 1]);
+    const bf16x8 b = __builtin_bit_cast(bf16x8, w);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v[s], b, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v[s], b, acc2, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void mma_acc_b2(const Frag<BEVR_PREC_F32>& a1, const Frag<BEVR_PREC_F32>& a2, const f32x16& x,
+                                           f32x16& acc1, f32x16& acc2) {
+  acc1 = mma_acc_b(a1, x, acc1);
+  acc2 = mma_acc_b(a2, x, acc2);
+}
+
+template <int PREC, bool SLOW>
+__global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
+    bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Kt,
+    const char* __restrict__ V, const char* __restrict__ key_ws, const char* __restrict__ table_pair,
+    const char* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
+    float* __restrict__ dQ, float* __restrict__ dtable) {
+  typedef LdsCQ<PREC> L;
+  constexpr int EB = L::EB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 staging buffers + a (Q, dO) fragment slot per wave
+
+  const int n_ph = d.n_prob * d.heads;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ph = (slot / d.S) * 8 + xcd;
+  if (ph >= n_ph) return;
+  const int j = slot % d.S;
+  const int prob = ph / d.heads, hd = ph % d.heads;
+  const int grp = hd / (d.heads / d.groups);
+  const int qb = prob / d.q_div;
+
+  const int tid = threadIdx.x, nt = blockDim.x, n_wave = nt >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lq = lane & 31, hi = lane >> 5;
+  const int Mp = d.S * d.Sp;
+  const int i0 = wave * 32;
+
+  const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB;
+  const char* dOh = dO + ((size_t)ph * Mp) * 32 * EB;
+  const char* Kh = K + ((size_t)ph * d.Np) * 32 * EB;
+  const char* Vh = V + ((size_t)ph * d.Np) * 32 * EB;
+  const char* Kth = Kt + ((size_t)ph * 32) * d.Np * EB;
+  const int pg = prob * d.groups + grp;
+  const char* kws = key_ws + (size_t)pg * d.Np * sizeof(KeyW);
+  const StepBox* kbox = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / 32);
+  const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
+  const int Hq = d.Hp + 1;
+  float* dtb = dtable + (size_t)hd * d.Wp * Hq;
+  const int Hp8 = d.Hp * 8;
+  const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
+  const float jrx = (float)j * rx;
+  const int n_step = d.Np / KT;
+  if constexpr (SLOW) {   // anything for this column?  (uniform: scalar loads of the tile boxes)
+    bool any = false;
+    for (int u = 0; u < 2 * n_step; ++u) {
+      const CellTile c = make_celltile(kbox[u], jrx);
+      any = any || (c.live && !c.fast);
+    }
+    if (!any) return;
+  }
+
+  // this lane's query; rows past the grid compute on a clamped copy with dO = delta = 0 (their dS is exactly 0)
+  const int qrow = i0 + lq;
+  const bool live = qrow < d.S;
+  const size_t mq = (size_t)j * d.Sp + min(qrow, d.S - 1);
+  const float lse = LSE[(size_t)ph * Mp + mq];
+  float dlt = delta[(size_t)ph * Mp + mq];
+  if (!live) dlt = 0.f;
+  // the Q and dO fragments live in LDS (own lanes' data, written and read by this wave only: no barrier), re-read per tile
+  char* qslot = smem + 2 * L::BUF + (wave * 64 + lane) * (64 * EB);
+  auto put_frag = [&](char* dst, const Frag<PREC>& f, bool zero) {
+    if constexpr (PREC == BEVR_PREC_BF16) {
+      const u32x4 z = {0, 0, 0, 0};
+      *reinterpret_cast<u32x4*>(dst) = zero ? z : __builtin_bit_cast(u32x4, f.v[0]);
+      *reinterpret_cast<u32x4*>(dst + 16) = zero ? z : __builtin_bit_cast(u32x4, f.v[1]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<f32x4*>(dst + 16 * k) =
+            zero ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{f.v[4 * k], f.v[4 * k + 1], f.v[4 * k + 2], f.v[4 * k + 3]};
+    }
+  };
+  auto get_frag = [&](const char* src, Frag<PREC>& f) {
+    if constexpr (PREC == BEVR_PREC_BF16) {
+      f.v[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src));
+      f.v[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + 16));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 16 * k);
+        f.v[4 * k] = t[0]; f.v[4 * k + 1] = t[1]; f.v[4 * k + 2] = t[2]; f.v[4 * k + 3] = t[3];
+      }
+    }
+  };
+  {
+    Frag<PREC> f;
+    f.load(Qh + mq * 32 * EB, hi);
+    put_frag(qslot, f, false);
+    f.load(dOh + mq * 32 * EB, hi);
+    put_frag(qslot + 32 * EB, f, !live);
+  }
+
+  f32x16 dq, y;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq[r] = 0.f; y[r] = 0.f; }
+
+  // ---- staging ---------------------------------------------------------------------------------------------
+  u32x4 st[L::NST];
+  const char* st_src[L::NST];
+  int st_inc[L::NST], st_dst[L::NST];
+#pragma unroll
+  for (int k = 0; k < L::NST; ++k) {
+    const int g = tid + k * nt;
+    st_dst[k] = -1;
+    st_src[k] = Kh;
+    st_inc[k] = 0;
+    if (g < L::NCH) chunk_map_q<PREC>(g, Kh, Vh, Kth, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
+  }
+  auto stage_load = [&](int step) {
+#pragma unroll
+    for (int k = 0; k < L::NST; ++k)
+      if (st_dst[k] >= 0) st[k] = *reinterpret_cast<const u32x4*>(st_src[k] + (size_t)step * st_inc[k]);
+  };
+  auto stage_store = [&](int buf, int step) {
+    char* base = smem + buf * L::BUF;
+#pragma unroll
+    for (int k = 0; k < L::NST; ++k)
+      if (st_dst[k] >= 0) *reinterpret_cast<u32x4*>(base + st_dst[k]) = st[k];
+    for (int g = tid + L::NST * nt; g < L::NCH; g += nt) {
+      const char* src;
+      int inc, dst;
+      chunk_map_q<PREC>(g, Kh, Vh, Kth, kws, d.Np, src, inc, dst);
+      *reinterpret_cast<u32x4*>(base + dst) = *reinterpret_cast<const u32x4*>(src + (size_t)step * inc);
+    }
+  };
+  // weights of tile t of a step, by this wave (lane & 31 = key): W for the bias product (lane = key) and its
+  // transpose for the table gradient (rows = chunk cells, 32 key positions in perm32 order)
+  auto build_w = [&](int buf, int step, int t, const KeyW& kw) {
+    const StepBox sb = kbox[2 * step + t];
+    const CellTile ct = make_celltile(sb, jrx);
+    float tcol, trow;
+    cell_coords(kw, jrx, ct.x0, step * KT + t * 32 + lq >= d.N, tcol, trow);
+    const CellFrag<PREC> w = cell_weights<PREC>(tcol, trow, hi);
+    char* bb = smem + buf * L::BUF;
+    char* dst = bb + L::OFF_W + (t * 64 + lane) * L::WL;
+    char* wt = bb + L::OFF_WT + t * L::WT_TILE + perm32(lq) * EB;
+    if constexpr (PREC == BEVR_PREC_BF16) {
+      const u32x4 wv = __builtin_bit_cast(u32x4, w.v);
+      *reinterpret_cast<u32x4*>(dst) = wv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {   // cell k' = 8 hi + e
+        const unsigned short hv = (unsigned short)(e & 1 ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu);
+        *reinterpret_cast<unsigned short*>(wt + (8 * hi + e) * L::WT_STRIDE) = hv;
+      }
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
+      *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
+#pragma unroll
+      for (int t8 = 0; t8 < 8; ++t8)   // cell k' = 2 t8 + hi
+        *reinterpret_cast<float*>(wt + (2 * t8 + hi) * L::WT_STRIDE) = w.v[t8];
+    }
+  };
+  auto load_kw = [&](int step, int t) {
+    return *reinterpret_cast<const KeyW*>(kws + ((size_t)step * KT + t * 32 + lq) * sizeof(KeyW));
+  };
+  auto builder_of = [&](int step, int t) { return (2 * step + t) % n_wave; };
+
+  // W^T rows 16..31 of every tile stay zero (a chunk has 16 cells; the MFMA tile has 32 rows)
+  for (int u = tid; u < 2 * 2 * 16 * (L::WT_STRIDE / 16); u += nt) {
+    const int q16 = u % (L::WT_STRIDE / 16), row = (u / (L::WT_STRIDE / 16)) % 16, tb = u / (16 * (L::WT_STRIDE / 16));
+    *reinterpret_cast<u32x4*>(smem + (tb >> 1) * L::BUF + L::OFF_WT + (tb & 1) * L::WT_TILE + (16 + row) * L::WT_STRIDE +
+                              q16 * 16) = u32x4{0, 0, 0, 0};
+  }
+  stage_load(0);
+  stage_store(0, 0);
+  if constexpr (!SLOW) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (builder_of(0, t) == wave) build_w(0, 0, t, load_kw(0, t));
+  }
+  __syncthreads();
+
+  CellFrag<PREC> tf;
+  int tag_x = 1 << 30, tag_a = 1 << 30;
+  if constexpr (PREC == BEVR_PREC_BF16) tf.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tf.v[k] = 0.f;
+  }
+
+  // add this wave's chunk of table gradient to HBM: register r of lane (i, hi) is chunk cell crow(r, hi) = 4 c + row,
+  // i.e. table entry (tag_x + c, tag_a + row + i0 + i); only cells < 16 exist
+  auto flush_y = [&]() {
+    if (tag_x != (1 << 30)) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int c = 2 * (r >> 2) + hi, row = r & 3;
+        const int xc = tag_x + c + d.x_off, yr = tag_a + row + i0 + lq + d.y_off;
+        const float v = y[r] * BEVR_LN2;
+        if (v != 0.f && xc >= 0 && xc < d.Wp && yr >= 0 && yr < Hq) atomicAdd(dtb + (size_t)xc * Hq + yr, v);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+  };
+
+  for (int step = 0; step < n_step; ++step) {
+    const int buf = step & 1;
+    const char* base = smem + buf * L::BUF;
+    const bool more = step + 1 < n_step;
+    if (more) stage_load(step + 1);
+    KeyW kwn[2];
+    bool bld[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bld[t] = !SLOW && more && builder_of(step + 1, t) == wave;
+      kwn[t] = KeyW{0, 0.f, 0.f, 0};
+      if (bld[t]) kwn[t] = load_kw(step + 1, t);
+    }
+    const KeyW* kwl = reinterpret_cast<const KeyW*>(base + L::OFF_KW);
+
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      const StepBox sb = kbox[2 * step + t];
+      const CellTile ct = make_celltile(sb, jrx);
+      if (!ct.live || (bool)ct.fast == SLOW) continue;   // nothing to do / the other pass's tile (uniform)
+      const bool last = (step == n_step - 1) && d.N < d.Np;
+
+      f32x16 s, dp;
+      {
+        float nl = -lse, nd = -dlt;
+        asm volatile("" : "+v"(nl), "+v"(nd));   // keep the splats inside the loop (attn_bwd_q.hip)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
+      }
+      {
+        Frag<PREC> kf, qf;
+        kf.load(base + (t * 32 + lq) * L::R_STRIDE, hi);
+        get_frag(qslot, qf);
+        s = mma_frag(kf, qf, s);   // S^T - LSE
+      }
+      {
+        Frag<PREC> vkf, dof;
+        vkf.load(base + L::OFF_V + (t * 32 + lq) * L::R_STRIDE, hi);
+        get_frag(qslot + 32 * EB, dof);
+        dp = mma_frag(vkf, dof, dp);   // dP^T - delta
+      }
+
+      if constexpr (!SLOW) {
+        if (ct.x0 != tag_x || ct.a0 != tag_a) {   // uniform: new chunk origin
+          flush_y();
+          tf = cell_table<PREC>(tbl, d, ct.x0, ct.a0 + i0 + lq, hi);
+          tag_x = ct.x0;
+          tag_a = ct.a0;
+        }
+        CellFrag<PREC> wf;
+        const char* wsrc = base + L::OFF_W + (t * 64 + lane) * L::WL;
+        if constexpr (PREC == BEVR_PREC_BF16) {
+          wf.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc));
+        } else {
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc), w1 = *reinterpret_cast<const f32x4*>(wsrc + 16);
+          wf.v[0] = w0[0]; wf.v[1] = w0[1]; wf.v[2] = w0[2]; wf.v[3] = w0[3];
+          wf.v[4] = w1[0]; wf.v[5] = w1[1]; wf.v[6] = w1[2]; wf.v[7] = w1[3];
+        }
+        s = mma_cell(wf, tf, s);
+        if (last) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = (step * KT + t * 32 + crow(r, hi) >= d.N) ? BEVR_NEG_BIG : s[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];   // P (dP - delta); ln2 applied on the way out
+        Frag<PREC> ktf, wtf;
+        load_perm(ktf, base + L::OFF_KT + lq * L::T_STRIDE + t * 32 * EB, hi);
+        load_perm(wtf, base + L::OFF_WT + t * L::WT_TILE + lq * L::WT_STRIDE, hi);
+        mma_acc_b2(ktf, wtf, s, dq, y);
+      } else {
+        // per-pair path: gathers from the table in global memory, float atomics into the table gradient
+        const int rowoff = (i0 + lq) * 8;
+        const int xoffHp = d.x_off * d.Hp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const KeyW c = kwl[t * 32 + crow(r, hi)];
+          const float wy0 = 1.0f - c.fy;
+          const float tx = jrx + c.b;
+          const float xf = floorf(tx);
+          const float fx = tx - xf;
+          const int xi = (int)xf;
+          const unsigned off = (unsigned)(xi * Hp8 + c.aoff + rowoff);
+          const f32x2 t0 = *reinterpret_cast<const f32x2*>(tbl + off);
+          const f32x2 t1 = *reinterpret_cast<const f32x2*>(tbl + off + Hp8);
+          const float u0 = t0[0] * wy0 + t0[1] * c.fy;
+          const float u1 = t1[0] * wy0 + t1[1] * c.fy;
+          float sv = s[r] + u0 + fx * (u1 - u0);
+          if (last && step * KT + t * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
+          const float ds = fast_exp2(sv) * dp[r];
+          s[r] = ds;
+          if (ds != 0.f) {
+            const int yi = (c.aoff >> 3) - xoffHp + i0 + lq;
+            float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
+            const float w0 = BEVR_LN2 * ds * (1.0f - fx), w1 = BEVR_LN2 * ds * fx;
+            atomicAdd(g0, w0 * wy0);
+            atomicAdd(g0 + 1, w0 * c.fy);
+            atomicAdd(g0 + Hq, w1 * wy0);
+            atomicAdd(g0 + Hq + 1, w1 * c.fy);
+          }
+          if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight (rare path, register budget)
+        }
+        Frag<PREC> ktf;
+        load_perm(ktf, base + L::OFF_KT + lq * L::T_STRIDE + t * 32 * EB, hi);
+        dq = mma_acc_b(ktf, s, dq);
+      }
+    }
+
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (bld[t]) build_w(buf ^ 1, step + 1, t, kwn[t]);
+      stage_store(buf ^ 1, step + 1);
+    }
+    __syncthreads();
+  }
+  if constexpr (!SLOW) flush_y();
+
+  // ---- dQ: added to what is there (the other key segment's share, or the caller's zeros) -----------------------
+  if (live) {
+    float* row = dQ + ((size_t)ph * Mp + (size_t)j * d.Sp + qrow) * 32;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * g4 + 4 * hi);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += BEVR_LN2 * dq[4 * g4 + k];
+      *reinterpret_cast<f32x4*>(row + 8 * g4 + 4 * hi) = v;
+    }
+  }
+}
+
+template <int PREC>
+int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt, const void* V, const void* key_ws,
+           const float* table_pair, const void* dO, const float* LSE, const float* delta, float* dQ, float* dtable,
+           hipStream_t st) {
+  const int n_ph = d.n_prob * d.heads;
+  const int grid = ((n_ph + 7) / 8) * 8 * d.S;
+  const int n_wave = d.Sp / 32;
+  const size_t lds = 2 * LdsCQ<PREC>::BUF + (size_t)n_wave * 64 * 64 * LdsCQ<PREC>::EB;
+  hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
+                     (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
+                     (const char*)dO, LSE, delta, dQ, dtable);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
+                     (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
+                     (const char*)dO, LSE, delta, dQ, dtable);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int bevr_attn_cell_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
+                                    const void* key_ws, const float* table_pair, const void* dO, const float* LSE,
+                                    const float* delta, float* dQ, float* dtable, void* stream) {
+  int rc = bevr_check_desc(d);
+  if (rc) return rc;
+  if (!Q || !K || !Kt || !V || !key_ws || !table_pair || !dO || !LSE || !delta || !dQ || !dtable) return BEVR_E_NULL;
+  if (d->Sp > 512) return BEVR_E_SHAPE;
+  if (!bevr_aligned16(Q) || !bevr_aligned16(K) || !bevr_aligned16(Kt) || !bevr_aligned16(V) || !bevr_aligned16(dO) ||
+      !bevr_aligned16(dQ) || !bevr_aligned16(table_pair) || !bevr_aligned16(key_ws))
+    return BEVR_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->precision == BEVR_PREC_BF16)
+    return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, dQ, dtable, st);
+  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, dQ, dtable, st);
+}

@@ -25,7 +25,7 @@ template <> __device__ __forceinline__ unsigned short to_elem<unsigned short>(fl
 // One workgroup = 64 consecutive keys of one problem, all heads, K and V.
 template <typename E>
 __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
-                                                      long long ld, int N, int Np, int heads, int c,
+                                                      long long ld, long long pstride, int N, int Np, int heads, int c,
                                                       E* __restrict__ Kr, E* __restrict__ Vr, E* __restrict__ Kt,
                                                       E* __restrict__ Vt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ 
     for (int i = tid; i < n_el; i += 256) tile[i] = to_elem<E>(0.f);
     __syncthreads();
   }
-  const float* src[2] = {koff + (size_t)b * N * ld, voff + (size_t)b * N * ld};
+  const float* src[2] = {koff + (size_t)b * pstride * ld, voff + (size_t)b * pstride * ld};
 #pragma unroll
   for (int kind = 0; kind < 2; ++kind) {
     for (int i = tid; i < PK * C; i += 256) {
@@ -88,14 +88,14 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ 
 // dK, dV [B'][h][Np][32] float (row layout) -> dk, dv rows (B', N, C) with row stride ld
 __global__ __launch_bounds__(256) void unpack_dkv_kernel(const float* __restrict__ dK, const float* __restrict__ dV,
                                                          float* __restrict__ dk, float* __restrict__ dv, long long ld,
-                                                         int N, int Np, int heads, int c) {
+                                                         long long pstride, int N, int Np, int heads, int c) {
   const int b = blockIdx.y, n0 = blockIdx.x * PK, tid = threadIdx.x;
   const int C = heads * c;
   for (int i = tid; i < PK * C; i += 256) {
     const int key = i / C, ch = i - key * C;
     if (n0 + key >= N) continue;
     const size_t s = (((size_t)b * heads + ch / c) * Np + n0 + key) * 32 + ch % c;
-    const size_t o = ((size_t)b * N + n0 + key) * ld + ch;
+    const size_t o = ((size_t)b * pstride + n0 + key) * ld + ch;
     dk[o] = dK[s];
     dv[o] = dV[s];
   }
@@ -103,10 +103,11 @@ __global__ __launch_bounds__(256) void unpack_dkv_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int bevr_pack_kv(const float* k, const float* v, long long ld, int n_prob, int N, int Np, int heads, int c,
-                            int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream) {
+extern "C" int bevr_pack_kv(const float* k, const float* v, long long ld, long long pstride, int n_prob, int N, int Np,
+                            int heads, int c, int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream) {
   if (!k || !v || !Kr || !Vr) return BEVR_E_NULL;
-  if (n_prob <= 0 || N <= 0 || Np < N || Np % PK || heads <= 0 || c <= 0 || c > 32 || ld < (long long)heads * c)
+  if (n_prob <= 0 || N <= 0 || Np < N || Np % PK || heads <= 0 || c <= 0 || c > 32 || ld < (long long)heads * c ||
+      pstride < N)
     return BEVR_E_SHAPE;
   if (precision != BEVR_PREC_BF16 && precision != BEVR_PREC_F32) return BEVR_E_PRECISION;
   if (!bevr_aligned16(Kr) || !bevr_aligned16(Vr) || (Kt && !bevr_aligned16(Kt)) || (Vt && !bevr_aligned16(Vt)))
@@ -117,20 +118,21 @@ extern "C" int bevr_pack_kv(const float* k, const float* v, long long ld, int n_
   const size_t lds = (size_t)2 * (heads < hg ? heads : hg) * PK * 32 * eb;
   hipStream_t st = (hipStream_t)stream;
   if (precision == BEVR_PREC_BF16)
-    hipLaunchKernelGGL(pack_kv_kernel<unsigned short>, grid, dim3(256), lds, st, k, v, ld, N, Np, heads, c,
+    hipLaunchKernelGGL(pack_kv_kernel<unsigned short>, grid, dim3(256), lds, st, k, v, ld, pstride, N, Np, heads, c,
                        (unsigned short*)Kr, (unsigned short*)Vr, (unsigned short*)Kt, (unsigned short*)Vt);
   else
-    hipLaunchKernelGGL(pack_kv_kernel<float>, grid, dim3(256), lds, st, k, v, ld, N, Np, heads, c, (float*)Kr,
+    hipLaunchKernelGGL(pack_kv_kernel<float>, grid, dim3(256), lds, st, k, v, ld, pstride, N, Np, heads, c, (float*)Kr,
                        (float*)Vr, (float*)Kt, (float*)Vt);
   return (int)hipGetLastError();
 }
 
-extern "C" int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, int n_prob, int N,
-                               int Np, int heads, int c, void* stream) {
+extern "C" int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, long long pstride,
+                               int n_prob, int N, int Np, int heads, int c, void* stream) {
   if (!dK || !dV || !dk || !dv) return BEVR_E_NULL;
-  if (n_prob <= 0 || N <= 0 || Np < N || Np % PK || heads <= 0 || c <= 0 || c > 32 || ld < (long long)heads * c)
+  if (n_prob <= 0 || N <= 0 || Np < N || Np % PK || heads <= 0 || c <= 0 || c > 32 || ld < (long long)heads * c ||
+      pstride < N)
     return BEVR_E_SHAPE;
   hipLaunchKernelGGL(unpack_dkv_kernel, dim3(Np / PK, n_prob), dim3(256), 0, (hipStream_t)stream, dK, dV, dk, dv, ld,
-                     N, Np, heads, c);
+                     pstride, N, Np, heads, c);
   return (int)hipGetLastError();
 }

@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from dataclasses import dataclass
+from dataclasses import dataclass, replace as dc_replace
 from typing import Optional, Tuple
 
 import torch
@@ -225,11 +225,6 @@ class _KernelTimer:
 KERNEL_TIMER = _KernelTimer()
 
 
-def _attn_flops(geom, n_matmul):
-    """algorithmic MFMA flops of one attention launch: 2 flop/MAC x head_dim 32 x query-key pairs."""
-    return 2.0 * HEAD_DIM * geom.n_prob * geom.heads * (geom.S * geom.S) * geom.N * n_matmul
-
-
 def _edtype(precision: int):
     return torch.bfloat16 if precision == _lib.PREC_BF16 else torch.float32
 
@@ -240,51 +235,103 @@ def _perm_t(x: torch.Tensor) -> torch.Tensor:
     return x.index_select(-2, perm_index(L, x.device)).transpose(-1, -2).contiguous()
 
 
+def _attn_flops(geom, n_matmul, n_keys=None):
+    """algorithmic MFMA flops of one attention launch: 2 flop/MAC x head_dim 32 x query-key pairs."""
+    n = geom.N if n_keys is None else n_keys
+    return 2.0 * HEAD_DIM * geom.n_prob * geom.heads * (geom.S * geom.S) * n * n_matmul
+
+
+def cell_order(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """The order that makes a key segment CELL-SORTED (csrc/attn_cell.h): per problem, keys sorted by rpe-table cell
+    (floor(a), floor(b)), rows ascending, columns boustrophedon (consecutive cells are neighbours).  a, b (P, N) table
+    coordinates -> (P, N) long.  Softmax attention is invariant to the order of its keys: the order only decides how
+    many 32-key tiles of the segment fit one table chunk."""
+    A = torch.floor(a).to(torch.int64)
+    Bc = torch.floor(b).to(torch.int64)
+    A = A - A.amin(1, keepdim=True)
+    Bc = Bc - Bc.amin(1, keepdim=True)
+    nB = Bc.amax(1, keepdim=True) + 1
+    snake = torch.where(A % 2 == 0, Bc, nB - 1 - Bc)
+    return (A * nB + snake).argsort(1)
+
+
+@dataclass
+class _Seg:
+    """One key segment of an attention call: keys [n0, n0 + geom.N) of the caller's arrays."""
+    cell: bool          # cell kernels (attn_cell_*.hip) or region kernels (attn_fwd.hip ...)
+    n0: int
+    geom: AttnGeom
+
+
 class _AttnCore(torch.autograd.Function):
-    """O = softmax(Q K^T + bias(a, b, table)) V in packed layouts (all inputs float32)."""
+    """O = softmax(Q K^T + bias(a, b, table)) V in packed layouts (all inputs float32).
+
+    The keys may be split into two segments that share one softmax: keys [0, split) go through the region kernels
+    (scattered keys: LDS table windows, per-pair bias gather), keys [split, N) through the cell kernels (keys the
+    caller sorted by table cell: bias as an MFMA).  The forward chains the segments through (O, LSE) in place; the
+    backward passes of both use the final LSE and delta and accumulate into the same dQ and d(table)."""
 
     @staticmethod
-    def forward(ctx, Qp, kv, key_a, key_b, Tt, geom: AttnGeom):
+    def forward(ctx, Qp, kv, key_a, key_b, Tt, geom: AttnGeom, split: int):
         _require_gpu(Qp, kv, key_a, key_b, Tt)
         L = _lib.lib()
         ed = _edtype(geom.precision)
         Qe = Qp.to(ed).contiguous()
-        # K | V rows (B', N, 2 h c) float -> the kernels' per-head layouts in one pass (csrc/pack.hip); the transposed K
-        # is only read by the backward
         kv = kv.float().contiguous()
-        C2 = kv.shape[-1]
+        N, C2 = kv.shape[1], kv.shape[-1]
         c = C2 // 2 // geom.heads
         dev = Qp.device
-        Ke = torch.empty(geom.n_prob, geom.heads, geom.Np, HEAD_DIM, device=dev, dtype=ed)
-        Ve = torch.empty_like(Ke)
-        Vt = torch.empty(geom.n_prob, geom.heads, HEAD_DIM, geom.Np, device=dev, dtype=ed)
-        Kt = torch.empty_like(Vt) if any(ctx.needs_input_grad) else None
-        _lib.check(L.bevr_pack_kv(_ptr(kv), C.c_void_p(kv.data_ptr() + 2 * C2), C2, geom.n_prob, geom.N, geom.Np,
-                                  geom.heads, c, geom.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _stream()),
-                   "bevr_pack_kv")
-        key_a, key_b = key_a.contiguous(), key_b.contiguous()
+        segs = []
+        if split > 0:
+            segs.append(_Seg(False, 0, dc_replace(geom, N=split)))
+        if split < N:
+            segs.append(_Seg(True, split, dc_replace(geom, N=N - split)))
         Ttc = Tt.contiguous()
         pair = torch.stack((Ttc[..., :-1], Ttc[..., 1:]), dim=-1).contiguous()   # (h, Wp, Hp, 2)
-        O = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=Qp.device, dtype=torch.float32)
+        O = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
         # plane 0: log2-sum-exp; plane 1: a bound of log2 of the row's largest softmax weight (rows past the grid: -inf here)
-        LSE = torch.full((2, geom.n_prob, geom.heads, geom.Mp), float("-inf"), device=Qp.device, dtype=torch.float32)
-        d = geom.desc()
-        # per-key table coordinates + per-step tap boxes, shared by the forward and the query-side backward
-        key_ws = torch.empty(L.bevr_attn_key_ws_bytes(C.byref(d)), device=Qp.device, dtype=torch.uint8)
-        _lib.check(L.bevr_attn_key_prep(C.byref(d), _ptr(key_a), _ptr(key_b), _ptr(key_ws), _stream()),
-                   "bevr_attn_key_prep")
-        _lib.check(KERNEL_TIMER.run("bevr_attn_fwd", _attn_flops(geom, 2), L.bevr_attn_fwd, C.byref(d), _ptr(Qe),
-                                    _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O), _ptr(LSE),
-                                    _stream()), "bevr_attn_fwd")
+        LSE = torch.full((2, geom.n_prob, geom.heads, geom.Mp), float("-inf"), device=dev, dtype=torch.float32)
+        need_bwd = any(ctx.needs_input_grad)
+        saved = []
+        for i, sg in enumerate(segs):
+            g = sg.geom
+            # K | V rows (B', N, 2 h c) float -> the kernels' per-head layouts in one pass (csrc/pack.hip); the
+            # transposed K is only read by the backward.  A segment is a row range of the caller's array (row stride C2,
+            # problem stride N rows): no copy.
+            Ke = torch.empty(g.n_prob, g.heads, g.Np, HEAD_DIM, device=dev, dtype=ed)
+            Ve = torch.empty_like(Ke)
+            Vt = torch.empty(g.n_prob, g.heads, HEAD_DIM, g.Np, device=dev, dtype=ed)
+            Kt = torch.empty_like(Vt) if need_bwd else None
+            kp = kv.data_ptr() + sg.n0 * C2 * 4
+            _lib.check(L.bevr_pack_kv(C.c_void_p(kp), C.c_void_p(kp + 2 * C2), C2, N, g.n_prob, g.N, g.Np, g.heads, c,
+                                      g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _stream()), "bevr_pack_kv")
+            ka = F.pad(key_a[:, sg.n0:sg.n0 + g.N], (0, g.Np - g.N)).contiguous()
+            kb = F.pad(key_b[:, sg.n0:sg.n0 + g.N], (0, g.Np - g.N)).contiguous()
+            d = g.desc()
+            # per-key table coordinates + per-tile tap boxes, shared by the forward and the backward passes
+            key_ws = torch.empty(L.bevr_attn_key_ws_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
+            _lib.check(L.bevr_attn_key_prep(C.byref(d), _ptr(ka), _ptr(kb), _ptr(key_ws), _stream()), "bevr_attn_key_prep")
+            if sg.cell:
+                o_in = _ptr(O) if i > 0 else None
+                l_in = _ptr(LSE) if i > 0 else None
+                _lib.check(KERNEL_TIMER.run("bevr_attn_cell_fwd", _attn_flops(g, 2), L.bevr_attn_cell_fwd, C.byref(d),
+                                            _ptr(Qe), _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), o_in, l_in, _ptr(O),
+                                            _ptr(LSE), _stream()), "bevr_attn_cell_fwd")
+            else:
+                _lib.check(KERNEL_TIMER.run("bevr_attn_fwd", _attn_flops(g, 2), L.bevr_attn_fwd, C.byref(d), _ptr(Qe),
+                                            _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O), _ptr(LSE),
+                                            _stream()), "bevr_attn_fwd")
+            saved += [Ke, Ve, Kt, ka, kb, key_ws]
         ctx.geom = geom
+        ctx.segs = segs
         ctx.kv_shape = kv.shape
-        ctx.save_for_backward(Qe, Ke, Ve, Kt, key_a, key_b, pair, O, LSE, key_ws)
+        ctx.save_for_backward(Qe, pair, O, LSE, *saved)
         return O
 
     @staticmethod
     def backward(ctx, dO):
         geom: AttnGeom = ctx.geom
-        Qe, Ke, Ve, Kt, key_a, key_b, pair, O, LSE, key_ws = ctx.saved_tensors
+        Qe, pair, O, LSE, *saved = ctx.saved_tensors
         L = _lib.lib()
         ed = _edtype(geom.precision)
         dO = dO.contiguous()
@@ -294,54 +341,78 @@ class _AttnCore(torch.autograd.Function):
         # 2^-9 |dO||V| -- pure noise in dQ, dK, d(pos), d(table) of a row dominated by one key)
         delta = (dOe.float() * O).sum(-1).contiguous()
         dev = dO.device
-        d = geom.desc()
-        # zeros: bwd_q walks the grid in 31-row tiles and never visits the padded rows S..Sp-1 of a column
+        # zeros: bwd_q walks the grid in 31-row tiles and never visits the padded rows S..Sp-1 of a column; the cell
+        # kernels add their segment's share
         dQ = torch.zeros(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
         dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
-        # fixed-point scale of the in-LDS table-gradient accumulation (include/bevrender_hip.h): a power of two s with
-        # s * bound <= 2^30, bound >= |P (dP - delta)| of every pair: |dP| = |dO_q . V_n| <= ||dO_q|| ||V_n||, and
-        # P <= Pmax, the largest softmax weight of the launch (forward, LSE plane 1; +0.05 in log2 for the rounding of
-        # the recomputed logits) -- with 10^5 keys per row Pmax is far below 1, and the unit that much finer.  The
-        # kernel applies s to dO and delta as it loads them (exact: a power of two) and ln2 / s when it stores.
-        # Stays on the device (no sync).
-        bound = dOe.float().norm(dim=-1).max() * Ve.float().norm(dim=-1).max() + delta.abs().max()
-        pmax_log2 = (LSE[1].max() + 0.05).clamp(-60.0, 0.0)
-        e = torch.floor(30.0 - torch.log2(bound.clamp_min(1e-30)) - pmax_log2).clamp(-100.0, 100.0)
-        gscale = torch.stack((torch.exp2(e), torch.exp2(-e))).contiguous()
-        _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(geom, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
-                                    _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
-                                    _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream()),
-                   "bevr_attn_bwd_q")
-        del Kt
-        dK = torch.empty(geom.n_prob, geom.heads, geom.Np, HEAD_DIM, device=dev, dtype=torch.float32)
-        dV = torch.empty_like(dK)
-        da = torch.zeros_like(key_a)
-        db = torch.zeros_like(key_b)
         Qt = _perm_t(Qe)
         dOt = _perm_t(dOe)
-        _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_k", _attn_flops(geom, 4), L.bevr_attn_bwd_k, C.byref(d), _ptr(Qe),
-                                    _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(key_a), _ptr(key_b), _ptr(pair), _ptr(dOe),
-                                    _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(dK), _ptr(dV), _ptr(da), _ptr(db),
-                                    _stream()), "bevr_attn_bwd_k")
+        N, C2 = ctx.kv_shape[1], ctx.kv_shape[-1]
+        dkv = torch.empty(ctx.kv_shape, device=dev, dtype=torch.float32)
+        das, dbs = [], []
+        for i, sg in enumerate(ctx.segs):
+            g = sg.geom
+            Ke, Ve, Kt, ka, kb, key_ws = saved[6 * i:6 * i + 6]
+            d = g.desc()
+            if sg.cell:
+                _lib.check(KERNEL_TIMER.run("bevr_attn_cell_bwd_q", _attn_flops(g, 3), L.bevr_attn_cell_bwd_q, C.byref(d),
+                                            _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
+                                            _ptr(LSE), _ptr(delta), _ptr(dQ), _ptr(dT), _stream()),
+                           "bevr_attn_cell_bwd_q")
+            else:
+                # fixed-point scale of the in-LDS table-gradient accumulation (include/bevrender_hip.h): a power of two s
+                # with s * bound <= 2^30, bound >= |P (dP - delta)| of every pair: |dP| = |dO_q . V_n| <= ||dO_q|| ||V_n||,
+                # and P <= Pmax, the largest softmax weight of the launch (forward, LSE plane 1; +0.05 in log2 for the
+                # rounding of the recomputed logits) -- with 10^5 keys per row Pmax is far below 1, and the unit that much
+                # finer.  The kernel applies s to dO and delta as it loads them (exact: a power of two) and ln2 / s when
+                # it stores.  Stays on the device (no sync).
+                bound = dOe.float().norm(dim=-1).max() * Ve.float().norm(dim=-1).max() + delta.abs().max()
+                pmax_log2 = (LSE[1].max() + 0.05).clamp(-60.0, 0.0)
+                e = torch.floor(30.0 - torch.log2(bound.clamp_min(1e-30)) - pmax_log2).clamp(-100.0, 100.0)
+                gscale = torch.stack((torch.exp2(e), torch.exp2(-e))).contiguous()
+                _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(g, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
+                                            _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
+                                            _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream()),
+                           "bevr_attn_bwd_q")
+            del Kt
+            dK = torch.empty(g.n_prob, g.heads, g.Np, HEAD_DIM, device=dev, dtype=torch.float32)
+            dV = torch.empty_like(dK)
+            da = torch.zeros_like(ka)
+            db = torch.zeros_like(kb)
+            if sg.cell:
+                _lib.check(KERNEL_TIMER.run("bevr_attn_cell_bwd_k", _attn_flops(g, 4), L.bevr_attn_cell_bwd_k, C.byref(d),
+                                            _ptr(Qe), _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
+                                            _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(dK), _ptr(dV), _ptr(da), _ptr(db),
+                                            _stream()), "bevr_attn_cell_bwd_k")
+            else:
+                _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_k", _attn_flops(g, 4), L.bevr_attn_bwd_k, C.byref(d), _ptr(Qe),
+                                            _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(ka), _ptr(kb), _ptr(pair), _ptr(dOe),
+                                            _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(dK), _ptr(dV), _ptr(da), _ptr(db),
+                                            _stream()), "bevr_attn_bwd_k")
+            # gradients of the row layout back to K | V rows (the adjoint of the packing), into the segment's rows
+            kp = dkv.data_ptr() + sg.n0 * C2 * 4
+            _lib.check(L.bevr_unpack_dkv(_ptr(dK), _ptr(dV), C.c_void_p(kp), C.c_void_p(kp + 2 * C2), C2, N, g.n_prob,
+                                         g.N, g.Np, g.heads, C2 // 2 // g.heads, _stream()), "bevr_unpack_dkv")
+            das.append(da[:, :g.N])
+            dbs.append(db[:, :g.N])
         if geom.q_div > 1:  # the views of one sample share the query: sum their query gradients
             dQ = dQ.reshape(geom.n_prob // geom.q_div, geom.q_div, geom.heads, geom.Mp, HEAD_DIM).sum(1)
-        # gradients of the row layout back to K | V rows (the adjoint of the packing)
-        dkv = torch.empty(ctx.kv_shape, device=dev, dtype=torch.float32)
-        C2 = dkv.shape[-1]
-        _lib.check(L.bevr_unpack_dkv(_ptr(dK), _ptr(dV), _ptr(dkv), C.c_void_p(dkv.data_ptr() + 2 * C2), C2,
-                                     geom.n_prob, geom.N, geom.Np, geom.heads, C2 // 2 // geom.heads, _stream()),
-                   "bevr_unpack_dkv")
-        return dQ, dkv, da, db, dT, None
+        da = das[0] if len(das) == 1 else torch.cat(das, 1)
+        db = dbs[0] if len(dbs) == 1 else torch.cat(dbs, 1)
+        return dQ, dkv, da, db, dT, None, None
 
 
 def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Optional[torch.Tensor], pos: torch.Tensor,
                    rpe_table: torch.Tensor, *, heads: int, groups: int, views: int, precision: int,
-                   kv: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   kv: Optional[torch.Tensor] = None, cell_split: Optional[int] = None) -> torch.Tensor:
     """Fused attention of the BEV query against sampled keys.
 
     query (B, C, S, S) layer-normed BEV query (used raw as Q); kproj, vproj (B*views, N, C) projected
     sampled features -- or `kv` (B*views, N, 2C) = K | V side by side, as one GEMM emits them (kproj = vproj = None);
     pos (B*views*groups, N, 2) key positions (y, x); rpe_table (h, 2S-1, Wt).
+    cell_split: keys [cell_split, N) are CELL-SORTED (cell_order: the caller ordered them by rpe-table cell) and go
+    through the cell kernels (bias as an MFMA), keys [0, cell_split) through the region kernels; None = N (no cell
+    segment).  Any split gives the same result; it only decides the speed.
     Returns (B*views, S*S, C): per view softmax(QK^T c^-0.5 + bias) V, rows in i*S + j order.
     Replaces model/SCA_deform_attn.py:304-413 / model/TSA_deform_attn.py:220-333.
     """
@@ -354,14 +425,19 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     if C2 != 2 * Cc:
         raise ValueError(f"K | V rows must have 2 x {Cc} channels, got {C2}")
     c = Cc // heads
+    split = N if cell_split is None else int(cell_split)
+    if not 0 <= split <= N:
+        raise ValueError("cell_split must lie in [0, N]")
     geom = AttnGeom(n_prob=Bp, q_div=views, heads=heads, groups=groups, S=S, N=N, Wt=rpe_table.shape[-1],
                     precision=precision)
+    if split < N and geom.Sp > 512:
+        split = N                       # the cell kernels run one wave per 32-row block of a BEV column, at most 16
     if rpe_table.shape[-2] != 2 * S - 1:
         raise ValueError("rpe_table height must be 2S-1")
     Qp = pack_query(query.float(), heads)
-    a, b = key_coords(pos.float(), S, geom.Wt, geom.Np)
+    a, b = key_coords(pos.float(), S, geom.Wt, N)
     Tt = pack_table(rpe_table.float(), geom)
-    O = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom)
+    O = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split)
     return unpack_out(O, S, c)
 
 

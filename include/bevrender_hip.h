@@ -19,6 +19,7 @@
  *   bevr_sample_fwd/bwd     F.grid_sample at model/SCA_deform_attn.py:290-301, model/TSA_deform_attn.py:210-217
  *   bevr_attn_fwd/bwd_*     model/SCA_deform_attn.py:331-413, model/TSA_deform_attn.py:245-333
  *                           (QK^T*scale + bilinear RPE bias + softmax + PV, never materialised)
+ *   bevr_attn_cell_*        the same lines, for key segments sorted by rpe-table cell (bias as a matrix product)
  *   bevr_pack_kv/unpack_dkv model/SCA_deform_attn.py:312-321 (projection outputs -> per-head operand layouts)
  *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
  *   bevr_offset_head_fwd/bwd  model/SCA_deform_attn.py:56-77, model/TSA_deform_attn.py:54-68 (offset heads, fused)
@@ -36,7 +37,10 @@
 extern "C" {
 #endif
 
-#define BEVR_ABI_VERSION 2
+/* 3: bevr_attn_fwd writes TWO LSE planes (round 2 changed that under version 2: a version-2 caller's [n_prob][heads][Mp]
+ *    buffer is too small), the key workspace carries group boxes, bevr_attn_bwd_q takes grad_scale; new: bevr_attn_cell_*,
+ *    problem strides of bevr_pack_kv / bevr_unpack_dkv. */
+#define BEVR_ABI_VERSION 3
 
 enum {
   BEVR_OK = 0,
@@ -145,6 +149,32 @@ int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, cons
                     float* dK, float* dV, float* dkey_a, float* dkey_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Cell-sorted key segments: the same attention with the relative-position bias (and its table gradient) as a small
+ * matrix product on the matrix cores (csrc/attn_cell.h).  Same descriptor, operand layouts, table, key workspace
+ * (bevr_attn_key_prep) and gradient semantics as the entry points above.  Fast when the keys of every aligned run
+ * of 32 span fewer than 4 table columns and 4 table rows including their second taps -- what sorting keys that
+ * crowd a few table cells by cell gives (the pillar points a camera does not see are all pinned to pixel (0, 0),
+ * model/bev_cmr_proj.py:76 of the reference: two thirds of an SCA view's keys) -- correct for any keys (runs that do
+ * not fit are gathered per pair from the table in global memory).  Requires Sp <= 512.
+ *
+ * One softmax over two key segments: run bevr_attn_fwd on the scattered keys, then bevr_attn_cell_fwd on the sorted
+ * ones with (O_in, LSE_in) = the first call's (O, LSE plane 0): the result is the softmax over both.  O_in == NULL:
+ * a single segment.  The backward entry points of both segments take the FINAL LSE and delta;
+ * bevr_attn_cell_bwd_q ADDS its share to dQ and dtable (call it after bevr_attn_bwd_q, or on zeroed buffers).
+ *   O_in [n_prob][heads][Mp][32] float, LSE_in [n_prob][heads][Mp] float; O, LSE as bevr_attn_fwd (LSE: 2 planes). */
+int bevr_attn_cell_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* Vt,
+                       const void* key_ws, const float* table_pair, const float* O_in, const float* LSE_in,
+                       float* O, float* LSE, void* stream);
+int bevr_attn_cell_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
+                         const void* key_ws, const float* table_pair, const void* dO, const float* LSE,
+                         const float* delta, float* dQ, float* dtable, void* stream);
+/* dK, dV written; dkey_a, dkey_b ACCUMULATED (as bevr_attn_bwd_k). */
+int bevr_attn_cell_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
+                         const void* key_ws, const float* table_pair, const void* dO, const void* dOt,
+                         const float* LSE, const float* delta, float* dK, float* dV, float* dkey_a, float* dkey_b,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Bilinear feature sampling, align_corners=True, zero padding (grid_sample semantics).
  *   feat [nb][Hi][Wi][C] float (channels-last)     pos [nb][N][2] float, (y, x) in [-1, 1] units
  *   out  [nb][N][C] float
@@ -205,16 +235,17 @@ int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
  * Operand packing for bevr_attn_* (the reshapes of model/SCA_deform_attn.py:312-321 / TSA_deform_attn.py:226-236:
  * proj_k / proj_v outputs -> per-head operands), one pass instead of a permute / pad / cast / transpose chain.
  *   k, v  rows (n_prob, N, heads*c) float with row stride ld floats (ld >= heads*c; K | V of one GEMM: ld = 2 heads c)
+ *         and problem stride pstride ROWS (pstride >= N; a key segment of a longer row array: pstride = its row count)
  *   Kr, Vr [n_prob][heads][Np][32] E   row layout: head_dim c <= 32 zero padded, keys N..Np-1 zero (Np % 64 == 0)
  *   Kt, Vt [n_prob][heads][32][Np] E   transposed, bits 2 <-> 3 of the in-32 key index swapped (either may be NULL)
  *   E = bf16 (BEVR_PREC_BF16, round to nearest even) or float (BEVR_PREC_F32).
  * bevr_unpack_dkv is the adjoint on the gradients of the row layout: dK, dV [n_prob][heads][Np][32] float ->
  * dk, dv rows (n_prob, N, heads*c) with row stride ld (every element of the rows written).
  * ---------------------------------------------------------------------------------------------- */
-int bevr_pack_kv(const float* k, const float* v, long long ld, int n_prob, int N, int Np, int heads, int c,
-                 int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream);
-int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, int n_prob, int N, int Np,
-                    int heads, int c, void* stream);
+int bevr_pack_kv(const float* k, const float* v, long long ld, long long pstride, int n_prob, int N, int Np, int heads,
+                 int c, int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream);
+int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, long long pstride, int n_prob,
+                    int N, int Np, int heads, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Offset heads of the deformable attention blocks, fused per BEV pixel (model/SCA_deform_attn.py:56-77 conv_offset_m{v};

@@ -148,15 +148,25 @@ def enclayer_s56_setup(device="cpu", precision=None):
     return mg, c, T, K, layer
 
 
+# gradients that are analytically zero: proj_k.bias shifts every logit of a query by the same amount and softmax is
+# shift invariant, so the reference's own value is rounding noise
+ANALYTIC_ZERO = ("proj_k.bias",)
+
+
 def check_sampled(z, name, g, rtol, atol_frac, floor_frac):
-    """Sampled entries of one gradient: |got - want| <= rtol |want| + atol_frac max|this gradient| + a floor relative
-    to the largest gradient of the fixture (proj_k.bias shifts every logit of a query equally: its true gradient
-    is 0 and the reference's value is rounding noise)."""
+    """Sampled entries of one gradient: |got - want| <= rtol |want| + atol_frac max|THIS gradient|.  No global floor: a
+    floor relative to the largest gradient of the fixture (648, an MLP weight) exceeded the whole magnitude of the small
+    tensors (d rpe_table 0.73, d prev_bev 0.65) in bf16 mode, so an all-zero gradient would have passed.
+    Only the analytically-zero gradients (ANALYTIC_ZERO) are held to a noise floor instead, floor_frac of the
+    fixture's largest gradient.  Returns err / absmax, or None for a noise tensor (not part of any 'worst' figure)."""
     idx, val, amax = z[name + ".idx"], z[name + ".val"], float(z[name + ".absmax"])
-    floor = floor_frac * max(float(z[str(n) + ".absmax"]) for n in z["names"])
     got = g.detach().flatten().cpu().numpy()[idx]
+    if name.endswith(ANALYTIC_ZERO):
+        floor = floor_frac * max(float(z[str(n) + ".absmax"]) for n in z["names"])
+        assert np.all(np.abs(got) <= floor + np.abs(val)), f"{name}: analytically zero, got {np.abs(got).max():.3e}"
+        return None
     err = np.abs(got - val).max() / (amax + 1e-30)
-    assert np.all(np.abs(got - val) <= rtol * np.abs(val) + atol_frac * amax + floor), f"{name}: err/absmax {err:.3e}"
+    assert np.all(np.abs(got - val) <= rtol * np.abs(val) + atol_frac * amax), f"{name}: err/absmax {err:.3e}"
     return err
 
 

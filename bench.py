@@ -102,11 +102,23 @@ class LiftBlock(nn.Module):
         return corr + bev.square().mean()
 
 
-def attn_flops(kind, geom):
-    """algorithmic MFMA flops of one attention launch (2 flop per MAC, head_dim 32)."""
-    pairs = geom.n_prob * geom.heads * (geom.S * geom.S) * geom.N
-    n_mm = {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4}[kind]
-    return 2.0 * 32 * pairs * n_mm
+# algorithmic matrix products per (query, key) pair of each attention entry point: QK^T + PV forward; S, dP, dQ on the
+# query side; S, dP, dV, dK on the key side.  The cell kernels' bias / table-gradient products are extra work the
+# formulation spends, not algorithmic flops: they are not counted.
+N_MATMUL = {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4,
+            "bevr_attn_cell_fwd": 2, "bevr_attn_cell_bwd_q": 3, "bevr_attn_cell_bwd_k": 4}
+
+
+def csrc_sha():
+    """Revision of the kernels: sha1 over the HIP sources (what profiles/*_traffic.json is tied to)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bevrender_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "bevrender_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
 
 
 def _oracle_params(C, h, D, V, S):
@@ -312,25 +324,30 @@ def main():
         dom = max(attn, key=lambda k: attn[k]["ms"]) if attn else None
         roof = None
         # HBM bytes per launch: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command (separate
-        # passes, gfx950 correction applied) by tools/measure_traffic.sh, which writes profiles/r02_traffic.json; only
-        # used when that file was measured at this batch / BEV side / precision
-        traffic_db = {}
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        # passes, gfx950 correction applied) by tools/measure_traffic.sh, which writes profiles/r03_traffic.json together
+        # with the kernel sources' sha; only attached when that file was measured at this batch / BEV side / precision
+        # AND on these very kernel sources (a stale file is not reported as measured traffic: ADVICE r02)
+        traffic_db, traffic_note = {}, "no profiles/r03_traffic.json for this batch / BEV side / precision"
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("batch") == B and tj.get("bev") == S and tj.get("precision") == args.precision:
-                traffic_db = tj["kernels"]
+                if tj.get("csrc_sha") == csrc_sha():
+                    traffic_db, traffic_note = tj["kernels"], f"measured at csrc_sha {tj.get('csrc_sha')}"
+                else:
+                    traffic_note = (f"profiles/r03_traffic.json was measured at csrc_sha {tj.get('csrc_sha')}, the kernels "
+                                    f"are at {csrc_sha()}: not attached")
         if dom:
             rec = attn[dom]
             avg_ms = rec["ms"] / rec["n"]
             flops = rec["flops"] / rec["n"]
             ach = flops / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.precision]
-            pairs = rec["flops"] / rec["n"] / (2.0 * 32 * {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4}[dom])
+            pairs = rec["flops"] / rec["n"] / (2.0 * 32 * N_MATMUL[dom])
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 5), "traffic": traffic_db.get(dom, {}).get("hbm_bytes_per_launch"),
-                    "avg_ms": round(avg_ms, 3), "launches": rec["n"],
+                    "traffic_note": traffic_note, "avg_ms": round(avg_ms, 3), "launches": rec["n"],
                     "pair_ops_per_s": round(pairs / (avg_ms * 1e-3), 0),
                     "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 2) for k, v in sorted(ktimes.items())},
                     "all_attention": {k: {"avg_ms": round(v["ms"] / v["n"], 3),
@@ -346,9 +363,10 @@ def main():
                               "bevr_attn_bwd_k": 6.0}    # per-lane tap gathers: 3 reads per 4 rows and table column
         roof_lds = []
         if args.precision == "bf16":
-            n_mm = {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4}
             for k, v in sorted(attn.items()):
-                prs = v["flops"] / (2.0 * 32 * n_mm[k]) / (v["ms"] * 1e-3)
+                if k not in LDS_CLK_PER_KEYROW:      # the cell kernels are not paced by per-pair LDS work
+                    continue
+                prs = v["flops"] / (2.0 * 32 * N_MATMUL[k]) / (v["ms"] * 1e-3)
                 peak_prs = N_CU * CLOCK_HZ * 64.0 / LDS_CLK_PER_KEYROW[k]
                 roof_lds.append({"bound": "lds", "kernel": k, "achieved": round(prs, 0), "peak": round(peak_prs, 0),
                                  "unit": "pairs/s", "frac": round(prs / peak_prs, 4),

@@ -22,6 +22,13 @@
 #pragma once
 #include "attn_tile.h"
 
+// 16-byte load through a pointer known to be global memory (a pointer that went through a lambda capture or a select
+// between kernel arguments is otherwise loaded with flat_load, which also counts on the LDS counter)
+__device__ __forceinline__ u32x4 gload16(const char* p) {
+  typedef const u32x4 __attribute__((address_space(1)))* gptr;
+  return *(gptr)(unsigned long long)p;
+}
+
 constexpr int CELL_C = 4;   // table columns per chunk
 constexpr int CELL_R = 4;   // table rows per chunk
 

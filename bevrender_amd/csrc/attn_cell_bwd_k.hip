@@ -15,6 +15,7 @@
 // neighbouring tiles sit in the same cells).  (Wave, column) combinations whose keys do not fit one chunk are left to a
 // second, SLOW pass of the same kernel (per-pair gather from the table in global memory, any key set; it ADDS its dK, dV to
 // the fast pass's, and its workgroups exit at once when none of their waves has such a column).
+#include <type_traits>
 #include "attn_cell.h"
 #include "attn_kstage.h"
 
@@ -134,10 +135,41 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
   for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
   float da = 0.f, db = 0.f;
 
-  // per BEV column: the chunk and this key's weights over it
+  // per BEV column: the chunk, this key's weights over it, and the chunk's table columns (clamped into the padded table
+  // once per column; per tile only the row offset changes)
   CellTile ct = make_celltile(sb, 0.f);
   CellFrag<PREC> wf, wyf, wxf;
   float jr = 0.f;
+  constexpr int NCOLP = PREC == BEVR_PREC_BF16 ? 2 : 4;   // table columns this lane half reads (attn_cell.h lane maps)
+  const char* colp[NCOLP];
+#pragma unroll
+  for (int c = 0; c < NCOLP; ++c) colp[c] = tbl;
+  // raw table entries of a tile's chunk for this lane: bf16 mode 2 columns x (T[y..y+1], T[y+2..y+3]); f32 mode 4 columns x
+  // (T[y + hi], T[y + hi + 2])
+  constexpr int NRAW = PREC == BEVR_PREC_BF16 ? 4 : 8;
+  typedef typename std::conditional<PREC == BEVR_PREC_BF16, f32x2, float>::type raw_t;
+  raw_t traw[NRAW];
+#pragma unroll
+  for (int k = 0; k < NRAW; ++k) traw[k] = raw_t{};
+  auto load_raw = [&](raw_t* dst, int rb_) {
+    // rows ct.a0 + rb * 32 + lq (+ 0..3): never below the padded table's first row (a0 >= -(Sp + 1), y_off = Sp + 2)
+    const int yr = ct.a0 + rb_ * 32 + lq + d.y_off;
+    if constexpr (PREC == BEVR_PREC_BF16) {
+      const int e0 = min(yr, d.Hp - 1) * 8, e2 = min(yr + 2, d.Hp - 1) * 8;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        dst[2 * c] = *reinterpret_cast<const f32x2*>(colp[c] + e0);
+        dst[2 * c + 1] = *reinterpret_cast<const f32x2*>(colp[c] + e2);
+      }
+    } else {
+      const int ea = min(yr + hi, d.Hp - 1) * 8, eb = min(yr + hi + 2, d.Hp - 1) * 8;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dst[2 * c] = *reinterpret_cast<const float*>(colp[c] + ea);
+        dst[2 * c + 1] = *reinterpret_cast<const float*>(colp[c] + eb);
+      }
+    }
+  };
 
   QStage<PREC, TWC, 1> qs;
   qs.init(tid, Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB, dO + ((size_t)ph * Mp) * 32 * EB,
@@ -166,8 +198,19 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
           cell_coords(kw, jr, ct.x0, dead, tcol, trow);
           wf = cell_weights<PREC>(tcol, trow, hi);
           cell_dweights<PREC>(tcol, trow, hi, wyf, wxf);
+#pragma unroll
+          for (int c = 0; c < NCOLP; ++c) {
+            const int xc = ct.x0 + (PREC == BEVR_PREC_BF16 ? 2 * hi + c : c) + d.x_off;
+            colp[c] = tbl + (size_t)max(0, min(xc, d.Wp - 1)) * Hp8;
+          }
         }
       }
+      // table operand of this (column, row block), lane = BEV row rb * 32 + lq: requested first, consumed after the
+      // S and dP products (global loads served by L1 / L2: the waves of the workgroup sit in the same cells)
+      // table operand of this (column, row block), lane = BEV row rb * 32 + lq: requested first, consumed after the S and
+      // dP products (global loads served by L1 / L2: the waves of the workgroup sit in the same cells).  Requesting it one
+      // tile ahead was tried: 8 more live registers, 11 spills, 28.5 -> 36.6 ms.
+      if constexpr (!SLOW) load_raw(traw, rb);
       const f32x4* rc = reinterpret_cast<const f32x4*>(base + 2 * L::TILE_Q + 2 * L::TILE_T);
       f32x16 s, dp;
       {
@@ -194,15 +237,24 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
       }
       float sa = 0.f, sbb = 0.f;
       if constexpr (!SLOW) {
-        // table operand of this (column, row block): lane = BEV row rb * 32 + lq
-        const CellFrag<PREC> tf = cell_table<PREC>(tbl, d, ct.x0, ct.a0 + rb * 32 + lq, hi);
+        CellFrag<PREC> tf;
+        if constexpr (PREC == BEVR_PREC_BF16) {
+          u32x4 w;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(traw[k][0], traw[k][1]);
+          tf.v = __builtin_bit_cast(bf16x8, w);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) tf.v[k] = traw[k];
+        }
         s = mma_cell(tf, wf, s);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float p = fast_exp2(s[r]);
-          if (any_dead) p = dead ? 0.f : p;
-          s[r] = p;
-          dp[r] *= p;   // dS = P (dP - delta); ln2 folded into the epilogue
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 pp = {fast_exp2(s[r]), fast_exp2(s[r + 1])};
+          if (any_dead) pp = dead ? f32x2{0.f, 0.f} : pp;
+          const f32x2 ds = pp * f32x2{dp[r], dp[r + 1]};   // dS = P (dP - delta); ln2 folded into the epilogue
+          s[r] = pp[0]; s[r + 1] = pp[1];
+          dp[r] = ds[0]; dp[r + 1] = ds[1];
         }
         // the two derivative products one after the other: they share 16 registers
         {

@@ -1,7 +1,7 @@
 // Attention backward, query side, over a CELL-SORTED key segment (attn_cell.h): dQ and the rpe-table gradient.
 // Counterpart of attn_bwd_q.hip for keys whose 32-key tiles fit one table chunk; same operand layouts, same gradient
 // semantics (include/bevrender_hip.h), same work split as attn_cell_fwd.hip (workgroup = one BEV column, waves = its
-// 32-row blocks).
+// 32-row blocks; one wave builds the next step's weights and tile geometry for all).
 //
 // The table gradient of a tile is the transpose of its bias product:
 //   dTsh[k'][i] += sum_n W[n][k'] dS^T[n][i]          (k' = chunk cell, i = BEV row of the lane)
@@ -10,9 +10,13 @@
 // no fixed point.  When the origin changes (3 % of the tiles of a cell-sorted segment) the wave adds its 16 cells x 32
 // rows to the table gradient in HBM with float atomics (32 consecutive rows of one table column per instruction and
 // lane half: two contiguous 128-byte runs).
+// VALU-bound like the forward: zero-accumulator MFMA chains, the row constants (-LSE, -delta) and P (dP - delta) as
+// packed f32 arithmetic.
 // Tiles that do not fit one chunk are left to a second, SLOW pass of the same kernel (per-pair gathers from the table in
-// global memory, float atomics; its workgroups exit at once when their column has no such tile).
+// global memory, float atomics): it lists its column's slow tiles, exits at once when there is none, and stages only
+// the listed tiles' steps.
 // dQ and dtable are ACCUMULATED: the region kernel (attn_bwd_q.hip) may have written the other key segment's share.
+#include <type_traits>
 #include "attn_cell.h"
 
 namespace {
@@ -28,14 +32,18 @@ template <int PREC> struct LdsCQ {
   static constexpr int W_BYTES = 2 * 64 * WL;
   static constexpr int WT_STRIDE = 32 * EB + 16;    // W^T rows: 32 key positions (perm32 order) per chunk cell
   static constexpr int WT_TILE = 32 * WT_STRIDE;    // 32 rows: cells 16..31 stay zero (one chunk = 16 cells)
-  static constexpr int BUF = 2 * R_BYTES + T_BYTES + KW_BYTES + W_BYTES + 2 * WT_TILE;
+  static constexpr int CT_BYTES = 2 * 16;
+  static constexpr int OFF_V = R_BYTES, OFF_KT = 2 * R_BYTES, OFF_KW = 2 * R_BYTES + T_BYTES, OFF_W = OFF_KW + KW_BYTES,
+                       OFF_WT = OFF_W + W_BYTES, OFF_CT = OFF_WT + 2 * WT_TILE;
+  static constexpr int OFF_DUMMY = OFF_CT + CT_BYTES;   // 16 B that idle staging threads write (keeps staging branch-free)
+  static constexpr int BUF = OFF_DUMMY + 16;
   static constexpr int RCH_ROW = 32 * EB / 16;
   static constexpr int TCH_ROW = KT * EB / 16;
   static constexpr int CH = KT * RCH_ROW;
   static constexpr int NCH = 3 * CH + KT;
   static constexpr int NST = PREC == BEVR_PREC_BF16 ? 2 : 4;
-  static constexpr int OFF_V = R_BYTES, OFF_KT = 2 * R_BYTES, OFF_KW = 2 * R_BYTES + T_BYTES, OFF_W = OFF_KW + KW_BYTES,
-                       OFF_WT = OFF_W + W_BYTES;
+  static constexpr int QCH = 32 * EB / 16 / 2;      // 16-B chunks of one lane's fragment: 2 (bf16) / 4 (f32)
+  static constexpr int QSLOT = 2 * QCH * 1024;      // per wave: Q then dO, each [chunk][lane]
 };
 
 template <int PREC>
@@ -89,7 +97,8 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
     float* __restrict__ dQ, float* __restrict__ dtable) {
   typedef LdsCQ<PREC> L;
   constexpr int EB = L::EB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 staging buffers + a (Q, dO) fragment slot per wave
+  // 2 staging buffers | a (Q, dO) fragment slot per wave | (slow pass) the list of this column's slow tiles
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int n_ph = d.n_prob * d.heads;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -120,13 +129,30 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
   const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
   const float jrx = (float)j * rx;
   const int n_step = d.Np / KT;
-  if constexpr (SLOW) {   // anything for this column?  (uniform: scalar loads of the tile boxes)
-    bool any = false;
-    for (int u = 0; u < 2 * n_step; ++u) {
+
+  char* qslot = smem + 2 * L::BUF + wave * L::QSLOT + lane * 16;
+  int* slow_list = reinterpret_cast<int*>(smem + 2 * L::BUF + n_wave * L::QSLOT);
+  __shared__ int slow_count;
+  if constexpr (SLOW) {
+    // this column's slow tiles, listed in key order: a flag byte per tile, then wave 0 compacts the flags with ballots
+    unsigned char* flag = reinterpret_cast<unsigned char*>(smem);   // the staging buffers are not in use yet
+    for (int u = tid; u < 2 * n_step; u += nt) {
       const CellTile c = make_celltile(kbox[u], jrx);
-      any = any || (c.live && !c.fast);
+      flag[u] = (c.live && !c.fast) ? 1 : 0;
     }
-    if (!any) return;
+    __syncthreads();
+    if (wave == 0) {
+      int cnt = 0;
+      for (int b0 = 0; b0 < 2 * n_step; b0 += 64) {
+        const bool f = b0 + lane < 2 * n_step && flag[b0 + lane];
+        const unsigned long long mask = __ballot(f);
+        if (f) slow_list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = b0 + lane;
+        cnt += __popcll(mask);
+      }
+      if (lane == 0) slow_count = cnt;
+    }
+    __syncthreads();
+    if (slow_count == 0) return;
   }
 
   // this lane's query; rows past the grid compute on a clamped copy with dO = delta = 0 (their dS is exactly 0)
@@ -136,28 +162,29 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
   const float lse = LSE[(size_t)ph * Mp + mq];
   float dlt = delta[(size_t)ph * Mp + mq];
   if (!live) dlt = 0.f;
-  // the Q and dO fragments live in LDS (own lanes' data, written and read by this wave only: no barrier), re-read per tile
-  char* qslot = smem + 2 * L::BUF + (wave * 64 + lane) * (64 * EB);
+  // the Q and dO fragments live in LDS (own lanes' data, written and read by this wave only: no barrier), re-read per
+  // tile; slot layout [chunk][lane]: consecutive lanes read consecutive 16 B (a per-lane slot of 64 / 128 B put 4 / 8
+  // lanes of a ds_read_b128 group on the same banks: measured 65 % of this kernel's LDS cycles)
   auto put_frag = [&](char* dst, const Frag<PREC>& f, bool zero) {
     if constexpr (PREC == BEVR_PREC_BF16) {
       const u32x4 z = {0, 0, 0, 0};
       *reinterpret_cast<u32x4*>(dst) = zero ? z : __builtin_bit_cast(u32x4, f.v[0]);
-      *reinterpret_cast<u32x4*>(dst + 16) = zero ? z : __builtin_bit_cast(u32x4, f.v[1]);
+      *reinterpret_cast<u32x4*>(dst + 1024) = zero ? z : __builtin_bit_cast(u32x4, f.v[1]);
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<f32x4*>(dst + 16 * k) =
+        *reinterpret_cast<f32x4*>(dst + 1024 * k) =
             zero ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{f.v[4 * k], f.v[4 * k + 1], f.v[4 * k + 2], f.v[4 * k + 3]};
     }
   };
   auto get_frag = [&](const char* src, Frag<PREC>& f) {
     if constexpr (PREC == BEVR_PREC_BF16) {
       f.v[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src));
-      f.v[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + 16));
+      f.v[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + 1024));
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 16 * k);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 1024 * k);
         f.v[4 * k] = t[0]; f.v[4 * k + 1] = t[1]; f.v[4 * k + 2] = t[2]; f.v[4 * k + 3] = t[3];
       }
     }
@@ -167,88 +194,12 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
     f.load(Qh + mq * 32 * EB, hi);
     put_frag(qslot, f, false);
     f.load(dOh + mq * 32 * EB, hi);
-    put_frag(qslot + 32 * EB, f, !live);
+    put_frag(qslot + L::QCH * 1024, f, !live);
   }
 
   f32x16 dq, y;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dq[r] = 0.f; y[r] = 0.f; }
-
-  // ---- staging ---------------------------------------------------------------------------------------------
-  u32x4 st[L::NST];
-  const char* st_src[L::NST];
-  int st_inc[L::NST], st_dst[L::NST];
-#pragma unroll
-  for (int k = 0; k < L::NST; ++k) {
-    const int g = tid + k * nt;
-    st_dst[k] = -1;
-    st_src[k] = Kh;
-    st_inc[k] = 0;
-    if (g < L::NCH) chunk_map_q<PREC>(g, Kh, Vh, Kth, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
-  }
-  auto stage_load = [&](int step) {
-#pragma unroll
-    for (int k = 0; k < L::NST; ++k)
-      if (st_dst[k] >= 0) st[k] = *reinterpret_cast<const u32x4*>(st_src[k] + (size_t)step * st_inc[k]);
-  };
-  auto stage_store = [&](int buf, int step) {
-    char* base = smem + buf * L::BUF;
-#pragma unroll
-    for (int k = 0; k < L::NST; ++k)
-      if (st_dst[k] >= 0) *reinterpret_cast<u32x4*>(base + st_dst[k]) = st[k];
-    for (int g = tid + L::NST * nt; g < L::NCH; g += nt) {
-      const char* src;
-      int inc, dst;
-      chunk_map_q<PREC>(g, Kh, Vh, Kth, kws, d.Np, src, inc, dst);
-      *reinterpret_cast<u32x4*>(base + dst) = *reinterpret_cast<const u32x4*>(src + (size_t)step * inc);
-    }
-  };
-  // weights of tile t of a step, by this wave (lane & 31 = key): W for the bias product (lane = key) and its
-  // transpose for the table gradient (rows = chunk cells, 32 key positions in perm32 order)
-  auto build_w = [&](int buf, int step, int t, const KeyW& kw) {
-    const StepBox sb = kbox[2 * step + t];
-    const CellTile ct = make_celltile(sb, jrx);
-    float tcol, trow;
-    cell_coords(kw, jrx, ct.x0, step * KT + t * 32 + lq >= d.N, tcol, trow);
-    const CellFrag<PREC> w = cell_weights<PREC>(tcol, trow, hi);
-    char* bb = smem + buf * L::BUF;
-    char* dst = bb + L::OFF_W + (t * 64 + lane) * L::WL;
-    char* wt = bb + L::OFF_WT + t * L::WT_TILE + perm32(lq) * EB;
-    if constexpr (PREC == BEVR_PREC_BF16) {
-      const u32x4 wv = __builtin_bit_cast(u32x4, w.v);
-      *reinterpret_cast<u32x4*>(dst) = wv;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {   // cell k' = 8 hi + e
-        const unsigned short hv = (unsigned short)(e & 1 ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu);
-        *reinterpret_cast<unsigned short*>(wt + (8 * hi + e) * L::WT_STRIDE) = hv;
-      }
-    } else {
-      *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
-      *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
-#pragma unroll
-      for (int t8 = 0; t8 < 8; ++t8)   // cell k' = 2 t8 + hi
-        *reinterpret_cast<float*>(wt + (2 * t8 + hi) * L::WT_STRIDE) = w.v[t8];
-    }
-  };
-  auto load_kw = [&](int step, int t) {
-    return *reinterpret_cast<const KeyW*>(kws + ((size_t)step * KT + t * 32 + lq) * sizeof(KeyW));
-  };
-  auto builder_of = [&](int step, int t) { return (2 * step + t) % n_wave; };
-
-  // W^T rows 16..31 of every tile stay zero (a chunk has 16 cells; the MFMA tile has 32 rows)
-  for (int u = tid; u < 2 * 2 * 16 * (L::WT_STRIDE / 16); u += nt) {
-    const int q16 = u % (L::WT_STRIDE / 16), row = (u / (L::WT_STRIDE / 16)) % 16, tb = u / (16 * (L::WT_STRIDE / 16));
-    *reinterpret_cast<u32x4*>(smem + (tb >> 1) * L::BUF + L::OFF_WT + (tb & 1) * L::WT_TILE + (16 + row) * L::WT_STRIDE +
-                              q16 * 16) = u32x4{0, 0, 0, 0};
-  }
-  stage_load(0);
-  stage_store(0, 0);
-  if constexpr (!SLOW) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (builder_of(0, t) == wave) build_w(0, 0, t, load_kw(0, t));
-  }
-  __syncthreads();
 
   CellFrag<PREC> tf;
   int tag_x = 1 << 30, tag_a = 1 << 30;
@@ -257,7 +208,6 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
 #pragma unroll
     for (int k = 0; k < 8; ++k) tf.v[k] = 0.f;
   }
-
   // add this wave's chunk of table gradient to HBM: register r of lane (i, hi) is chunk cell crow(r, hi) = 4 c + row,
   // i.e. table entry (tag_x + c, tag_a + row + i0 + i); only cells < 16 exist
   auto flush_y = [&]() {
@@ -274,122 +224,237 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
     for (int r = 0; r < 16; ++r) y[r] = 0.f;
   };
 
-  for (int step = 0; step < n_step; ++step) {
-    const int buf = step & 1;
-    const char* base = smem + buf * L::BUF;
-    const bool more = step + 1 < n_step;
-    if (more) stage_load(step + 1);
-    KeyW kwn[2];
-    bool bld[2];
+  // ---- one tile ------------------------------------------------------------------------------------------------
+  // MASKED: the tile may hold padded keys (last step only); its own instantiation (attn_cell_fwd.hip)
+  auto tile = [&](auto masked_tag, const char* base, int step, int t, int x0, int a0) {
+    constexpr bool last = decltype(masked_tag)::value;
+    f32x16 s, dp;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      bld[t] = !SLOW && more && builder_of(step + 1, t) == wave;
-      kwn[t] = KeyW{0, 0.f, 0.f, 0};
-      if (bld[t]) kwn[t] = load_kw(step + 1, t);
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }   // literal-zero accumulators: no register splats
+    {
+      Frag<PREC> kf, qf;
+      kf.load(base + (t * 32 + lq) * L::R_STRIDE, hi);
+      get_frag(qslot, qf);
+      s = mma_frag(kf, qf, s);   // S^T
     }
-    const KeyW* kwl = reinterpret_cast<const KeyW*>(base + L::OFF_KW);
+    {
+      Frag<PREC> vkf, dof;
+      vkf.load(base + L::OFF_V + (t * 32 + lq) * L::R_STRIDE, hi);
+      get_frag(qslot + L::QCH * 1024, dof);
+      dp = mma_frag(vkf, dof, dp);   // dP^T
+    }
+    if constexpr (!SLOW) {
+      if (x0 != tag_x || a0 != tag_a) {   // uniform: new chunk origin
+        flush_y();
+        tf = cell_table<PREC>(tbl, d, x0, a0 + i0 + lq, hi);
+        tag_x = x0;
+        tag_a = a0;
+      }
+      CellFrag<PREC> wf;
+      const char* wsrc = base + L::OFF_W + (t * 64 + lane) * L::WL;
+      if constexpr (PREC == BEVR_PREC_BF16) {
+        wf.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc));
+      } else {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc), w1 = *reinterpret_cast<const f32x4*>(wsrc + 16);
+        wf.v[0] = w0[0]; wf.v[1] = w0[1]; wf.v[2] = w0[2]; wf.v[3] = w0[3];
+        wf.v[4] = w1[0]; wf.v[5] = w1[1]; wf.v[6] = w1[2]; wf.v[7] = w1[3];
+      }
+      s = mma_cell(wf, tf, s);
+      if constexpr (last) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = (step * KT + t * 32 + crow(r, hi) >= d.N) ? BEVR_NEG_BIG : s[r];
+      }
+      // P = exp2(S - LSE), dS = P (dP - delta), two rows per instruction; ln2 applied on the way out
+      const f32x2 nl = {-lse, -lse}, nd = {-dlt, -dlt};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sh = f32x2{s[r], s[r + 1]} + nl;
+        const f32x2 pp = {fast_exp2(sh[0]), fast_exp2(sh[1])};
+        const f32x2 ds = pp * (f32x2{dp[r], dp[r + 1]} + nd);
+        s[r] = ds[0];
+        s[r + 1] = ds[1];
+      }
+      Frag<PREC> ktf, wtf;
+      load_perm(ktf, base + L::OFF_KT + lq * L::T_STRIDE + t * 32 * EB, hi);
+      load_perm(wtf, base + L::OFF_WT + t * L::WT_TILE + lq * L::WT_STRIDE, hi);
+      mma_acc_b2(ktf, wtf, s, dq, y);
+    } else {
+      // per-pair path: gathers from the table in global memory, float atomics into the table gradient
+      const KeyW* kwl = reinterpret_cast<const KeyW*>(base + L::OFF_KW);
+      const int rowoff = (i0 + lq) * 8;
+      const int xoffHp = d.x_off * d.Hp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const KeyW c = kwl[t * 32 + crow(r, hi)];
+        const float wy0 = 1.0f - c.fy;
+        const float tx = jrx + c.b;
+        const float xf = floorf(tx);
+        const float fx = tx - xf;
+        const int xi = (int)xf;
+        const unsigned off = (unsigned)(xi * Hp8 + c.aoff + rowoff);
+        const f32x2 t0 = *reinterpret_cast<const f32x2*>(tbl + off);
+        const f32x2 t1 = *reinterpret_cast<const f32x2*>(tbl + off + Hp8);
+        const float u0 = t0[0] * wy0 + t0[1] * c.fy;
+        const float u1 = t1[0] * wy0 + t1[1] * c.fy;
+        float sv = s[r] - lse + u0 + fx * (u1 - u0);
+        if (last && step * KT + t * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
+        const float ds = fast_exp2(sv) * (dp[r] - dlt);
+        s[r] = ds;
+        if (ds != 0.f) {
+          const int yi = (c.aoff >> 3) - xoffHp + i0 + lq;
+          float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
+          const float w0 = BEVR_LN2 * ds * (1.0f - fx), w1 = BEVR_LN2 * ds * fx;
+          atomicAdd(g0, w0 * wy0);
+          atomicAdd(g0 + 1, w0 * c.fy);
+          atomicAdd(g0 + Hq, w1 * wy0);
+          atomicAdd(g0 + Hq + 1, w1 * c.fy);
+        }
+        if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight (register budget)
+      }
+      Frag<PREC> ktf;
+      load_perm(ktf, base + L::OFF_KT + lq * L::T_STRIDE + t * 32 * EB, hi);
+      dq = mma_acc_b(ktf, s, dq);
+    }
+  };
+
+  // ---- staging helpers -----------------------------------------------------------------------------------------
+  u32x4 st[L::NST];
+  const char* st_src[L::NST];
+  int st_inc[L::NST], st_dst[L::NST];
+#pragma unroll
+  for (int k = 0; k < L::NST; ++k) {
+    const int g = tid + k * nt;
+    // threads beyond the chunk count re-read chunk 0 into a dummy slot: loads and stores stay unconditional
+    chunk_map_q<PREC>(g < L::NCH ? g : 0, Kh, Vh, Kth, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
+    if (g >= L::NCH) st_dst[k] = L::OFF_DUMMY;
+  }
+  auto stage_direct = [&](char* base, int step, int g0) {
+    for (int g = g0; g < L::NCH; g += nt) {
+      const char* src;
+      int inc, dst;
+      chunk_map_q<PREC>(g, Kh, Vh, Kth, kws, d.Np, src, inc, dst);
+      *reinterpret_cast<u32x4*>(base + dst) = *reinterpret_cast<const u32x4*>(src + (size_t)step * inc);
+    }
+  };
+
+  if constexpr (SLOW) {
+    const int n_slow = slow_count;
+    for (int u = 0; u < n_slow; ++u) {
+      const int tile_id = slow_list[u];
+      const int step = tile_id >> 1, t = tile_id & 1;
+      __syncthreads();                  // every wave is done with the previous tile's buffer
+      stage_direct(smem, step, tid);
+      __syncthreads();
+      if (step == n_step - 1 && d.N < d.Np) tile(std::true_type{}, smem, step, t, 0, 0);
+      else tile(std::false_type{}, smem, step, t, 0, 0);
+    }
+  } else {
+    // weights of tile t of a step, by this wave (lane & 31 = key): W for the bias product (lane = key), its transpose for
+    // the table gradient (rows = chunk cells, 32 key positions in perm32 order), and the tile's geometry
+    auto build_w = [&](int buf, int step, int t, const KeyW& kw, const StepBox& sb) {
+      const CellTile ct = make_celltile(sb, jrx);
+      float tcol, trow;
+      cell_coords(kw, jrx, ct.x0, step * KT + t * 32 + lq >= d.N, tcol, trow);
+      const CellFrag<PREC> w = cell_weights<PREC>(tcol, trow, hi);
+      char* bb = smem + buf * L::BUF;
+      char* dst = bb + L::OFF_W + (t * 64 + lane) * L::WL;
+      char* wt = bb + L::OFF_WT + t * L::WT_TILE + perm32(lq) * EB;
+      if constexpr (PREC == BEVR_PREC_BF16) {
+        const u32x4 wv = __builtin_bit_cast(u32x4, w.v);
+        *reinterpret_cast<u32x4*>(dst) = wv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {   // cell k' = 8 hi + e
+          const unsigned short hv = (unsigned short)(e & 1 ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu);
+          *reinterpret_cast<unsigned short*>(wt + (8 * hi + e) * L::WT_STRIDE) = hv;
+        }
+      } else {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
+        *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8)   // cell k' = 2 t8 + hi
+          *reinterpret_cast<float*>(wt + (2 * t8 + hi) * L::WT_STRIDE) = w.v[t8];
+      }
+      if (lane == 0) *reinterpret_cast<CellTile*>(bb + L::OFF_CT + t * 16) = ct;
+    };
+    auto load_kw = [&](int step, int t) {
+      return *reinterpret_cast<const KeyW*>(kws + ((size_t)step * KT + t * 32 + lq) * sizeof(KeyW));
+    };
+    auto builder_of = [&](int step, int t) { return (2 * step + t) % n_wave; };
+
+    // W^T rows 16..31 of every tile stay zero (a chunk has 16 cells; the MFMA tile has 32 rows)
+    for (int u = tid; u < 2 * 2 * 16 * (L::WT_STRIDE / 16); u += nt) {
+      const int q16 = u % (L::WT_STRIDE / 16), row = (u / (L::WT_STRIDE / 16)) % 16, tb = u / (16 * (L::WT_STRIDE / 16));
+      *reinterpret_cast<u32x4*>(smem + (tb >> 1) * L::BUF + L::OFF_WT + (tb & 1) * L::WT_TILE +
+                                (16 + row) * L::WT_STRIDE + q16 * 16) = u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < L::NST; ++k)
+      *reinterpret_cast<u32x4*>(smem + st_dst[k]) = gload16(st_src[k]);
+    stage_direct(smem, 0, tid + L::NST * nt);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (builder_of(0, t) == wave) build_w(0, 0, t, load_kw(0, t), kbox[t]);
+    __syncthreads();
+
+    StepBox sb_nxt[2] = {kbox[2 * min(1, n_step - 1)], kbox[2 * min(1, n_step - 1) + 1]};
+    // a last step with padded keys is peeled off behind the loop (its masked tile body inside the loop cost every tile
+    // registers or hoisted compares)
+    const int n_main = d.N < d.Np ? n_step - 1 : n_step;
+    for (int step = 0; step < n_main; ++step) {
+      const int buf = step & 1;
+      const char* base = smem + buf * L::BUF;
+      const bool more = step + 1 < n_step;
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < L::NST; ++k) {
+          st_src[k] += st_inc[k];
+          st[k] = gload16(st_src[k]);
+        }
+      }
+      // the next step's key record for the tile this wave builds: unconditional load, consumed after the tiles
+      // (attn_cell_fwd.hip); a wave builds at most one tile of a step (two only when it is the only wave)
+      const int nstep_c = min(step + 1, n_step - 1);
+      const int tb = builder_of(step + 1, 1) == wave ? 1 : 0;
+      const bool bld = more && builder_of(step + 1, tb) == wave;
+      const KeyW kwn = load_kw(nstep_c, tb);
+      const StepBox sbb = sb_nxt[tb];
+      const StepBox sbo = sb_nxt[1 - tb];
+      sb_nxt[0] = kbox[2 * min(step + 2, n_step - 1)];
+      sb_nxt[1] = kbox[2 * min(step + 2, n_step - 1) + 1];
 
 #pragma unroll 1
-    for (int t = 0; t < 2; ++t) {
-      const StepBox sb = kbox[2 * step + t];
-      const CellTile ct = make_celltile(sb, jrx);
-      if (!ct.live || (bool)ct.fast == SLOW) continue;   // nothing to do / the other pass's tile (uniform)
-      const bool last = (step == n_step - 1) && d.N < d.Np;
-
-      f32x16 s, dp;
-      {
-        float nl = -lse, nd = -dlt;
-        asm volatile("" : "+v"(nl), "+v"(nd));   // keep the splats inside the loop (attn_bwd_q.hip)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
-      }
-      {
-        Frag<PREC> kf, qf;
-        kf.load(base + (t * 32 + lq) * L::R_STRIDE, hi);
-        get_frag(qslot, qf);
-        s = mma_frag(kf, qf, s);   // S^T - LSE
-      }
-      {
-        Frag<PREC> vkf, dof;
-        vkf.load(base + L::OFF_V + (t * 32 + lq) * L::R_STRIDE, hi);
-        get_frag(qslot + 32 * EB, dof);
-        dp = mma_frag(vkf, dof, dp);   // dP^T - delta
+      for (int t = 0; t < 2; ++t) {
+        const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);   // geometry, by the builder
+        const int live = __builtin_amdgcn_readfirstlane((int)cw[0]), fast = __builtin_amdgcn_readfirstlane((int)cw[1]);
+        if (!live || !fast) continue;   // nothing to do / the slow pass's tile (uniform)
+        tile(std::false_type{}, base, step, t, __builtin_amdgcn_readfirstlane((int)cw[2]),
+             __builtin_amdgcn_readfirstlane((int)cw[3]));
       }
 
-      if constexpr (!SLOW) {
-        if (ct.x0 != tag_x || ct.a0 != tag_a) {   // uniform: new chunk origin
-          flush_y();
-          tf = cell_table<PREC>(tbl, d, ct.x0, ct.a0 + i0 + lq, hi);
-          tag_x = ct.x0;
-          tag_a = ct.a0;
-        }
-        CellFrag<PREC> wf;
-        const char* wsrc = base + L::OFF_W + (t * 64 + lane) * L::WL;
-        if constexpr (PREC == BEVR_PREC_BF16) {
-          wf.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc));
-        } else {
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc), w1 = *reinterpret_cast<const f32x4*>(wsrc + 16);
-          wf.v[0] = w0[0]; wf.v[1] = w0[1]; wf.v[2] = w0[2]; wf.v[3] = w0[3];
-          wf.v[4] = w1[0]; wf.v[5] = w1[1]; wf.v[6] = w1[2]; wf.v[7] = w1[3];
-        }
-        s = mma_cell(wf, tf, s);
-        if (last) {
+      if (more) {
+        if (bld) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
+        if (n_wave == 1) build_w(buf ^ 1, step + 1, 1 - tb, load_kw(step + 1, 1 - tb), sbo);
+        char* nb = smem + (buf ^ 1) * L::BUF;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[r] = (step * KT + t * 32 + crow(r, hi) >= d.N) ? BEVR_NEG_BIG : s[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];   // P (dP - delta); ln2 applied on the way out
-        Frag<PREC> ktf, wtf;
-        load_perm(ktf, base + L::OFF_KT + lq * L::T_STRIDE + t * 32 * EB, hi);
-        load_perm(wtf, base + L::OFF_WT + t * L::WT_TILE + lq * L::WT_STRIDE, hi);
-        mma_acc_b2(ktf, wtf, s, dq, y);
-      } else {
-        // per-pair path: gathers from the table in global memory, float atomics into the table gradient
-        const int rowoff = (i0 + lq) * 8;
-        const int xoffHp = d.x_off * d.Hp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const KeyW c = kwl[t * 32 + crow(r, hi)];
-          const float wy0 = 1.0f - c.fy;
-          const float tx = jrx + c.b;
-          const float xf = floorf(tx);
-          const float fx = tx - xf;
-          const int xi = (int)xf;
-          const unsigned off = (unsigned)(xi * Hp8 + c.aoff + rowoff);
-          const f32x2 t0 = *reinterpret_cast<const f32x2*>(tbl + off);
-          const f32x2 t1 = *reinterpret_cast<const f32x2*>(tbl + off + Hp8);
-          const float u0 = t0[0] * wy0 + t0[1] * c.fy;
-          const float u1 = t1[0] * wy0 + t1[1] * c.fy;
-          float sv = s[r] + u0 + fx * (u1 - u0);
-          if (last && step * KT + t * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
-          const float ds = fast_exp2(sv) * dp[r];
-          s[r] = ds;
-          if (ds != 0.f) {
-            const int yi = (c.aoff >> 3) - xoffHp + i0 + lq;
-            float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
-            const float w0 = BEVR_LN2 * ds * (1.0f - fx), w1 = BEVR_LN2 * ds * fx;
-            atomicAdd(g0, w0 * wy0);
-            atomicAdd(g0 + 1, w0 * c.fy);
-            atomicAdd(g0 + Hq, w1 * wy0);
-            atomicAdd(g0 + Hq + 1, w1 * c.fy);
-          }
-          if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight (rare path, register budget)
-        }
-        Frag<PREC> ktf;
-        load_perm(ktf, base + L::OFF_KT + lq * L::T_STRIDE + t * 32 * EB, hi);
-        dq = mma_acc_b(ktf, s, dq);
+        for (int k = 0; k < L::NST; ++k)
+          *reinterpret_cast<u32x4*>(nb + st_dst[k]) = st[k];
+        stage_direct(nb, step + 1, tid + L::NST * nt);
+      }
+      __syncthreads();
+    }
+    if (n_main < n_step) {   // the peeled last step: padded keys masked
+      const char* base = smem + (n_main & 1) * L::BUF;
+#pragma unroll 1
+      for (int t = 0; t < 2; ++t) {
+        const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);
+        const int live = __builtin_amdgcn_readfirstlane((int)cw[0]), fast = __builtin_amdgcn_readfirstlane((int)cw[1]);
+        if (!live || !fast) continue;
+        tile(std::true_type{}, base, n_main, t, __builtin_amdgcn_readfirstlane((int)cw[2]),
+             __builtin_amdgcn_readfirstlane((int)cw[3]));
       }
     }
-
-    if (more) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if (bld[t]) build_w(buf ^ 1, step + 1, t, kwn[t]);
-      stage_store(buf ^ 1, step + 1);
-    }
-    __syncthreads();
+    flush_y();
   }
-  if constexpr (!SLOW) flush_y();
 
   // ---- dQ: added to what is there (the other key segment's share, or the caller's zeros) -----------------------
   if (live) {
@@ -408,18 +473,21 @@ template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt, const void* V, const void* key_ws,
            const float* table_pair, const void* dO, const float* LSE, const float* delta, float* dQ, float* dtable,
            hipStream_t st) {
+  typedef LdsCQ<PREC> L;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * d.S;
   const int n_wave = d.Sp / 32;
-  const size_t lds = 2 * LdsCQ<PREC>::BUF + (size_t)n_wave * 64 * 64 * LdsCQ<PREC>::EB;
+  const size_t lds = 2 * L::BUF + (size_t)n_wave * L::QSLOT;
+  const size_t lds_slow = lds + (size_t)(d.Np / 32) * 4;
+  if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
   hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
                      (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
                      (const char*)dO, LSE, delta, dQ, dtable);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
-                     (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
-                     (const char*)dO, LSE, delta, dQ, dtable);
+  hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d,
+                     (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
+                     (const char*)table_pair, (const char*)dO, LSE, delta, dQ, dtable);
   return (int)hipGetLastError();
 }
 

@@ -1,28 +1,37 @@
 // Attention forward over a CELL-SORTED key segment (attn_cell.h): O = softmax_n(Q^T K scale + rpe bias) V with the
 // bias of a (32 keys x 32 BEV rows) tile as ONE extra MFMA.  Same arithmetic as attn_fwd.hip
 // (model/SCA_deform_attn.py:331-413 of the reference), same operand layouts, same orientation (S^T[key][query],
-// query on the lane, lazily rescaled online softmax, P^T fed back as the B operand of PV).
+// query on the lane, online softmax, P^T fed back as the B operand of PV).
 //
 // Work split: workgroup = ONE BEV column j of one (problem, head); its waves are the column's 32-row blocks, so every
-// wave needs the same per-(column, key) weights W: one wave builds them for the next step (its lanes = the keys, rotating
-// over the waves) while all waves compute the current one, and they are handed over in LDS with the staged K / V^T tiles
+// wave needs the same per-(column, key) weights W and the same tile geometry: one wave (rotating) builds both for the
+// next step while all waves compute the current one, and they are handed over in LDS with the staged K / V^T tiles
 // (one barrier per 64-key step).  A wave reloads its table operand only when the chunk origin changes (3 % of the
 // tiles of a cell-sorted segment).
 //
+// The kernel is VALU-bound (a wave64 VALU instruction holds the SIMD ~4.4 clk; measured, profiles/r03_pmc_*), so the
+// tile body is written for instruction count: the MFMA chains start from a literal-zero accumulator and the row
+// constant is subtracted with packed adds; there is no running-max chain -- P = exp2(S - m) is formed against the
+// reference m as it stands, the tile is committed, and m is moved up AFTERWARDS when the tile's mass exceeds 4 (so every
+// committed weight is <= 4 relative to the final m, as in attn_fwd.hip); only a tile whose mass overflows (logits
+// more than ~60 above m: the first tile, or an adversarial jump) is redone with its exact maximum.
+//
 // Two passes (template parameter SLOW): the fast pass computes the tiles that fit one chunk and skips the others; the slow
-// pass then visits ONLY the skipped tiles (per-pair gather from the table in global memory; correct for any key set),
-// continuing the softmax in place from the fast pass's (O, LSE) -- and its workgroups exit at once when their column has
-// no such tile, which is the normal case for a cell-sorted segment.  One kernel with both paths in its tile loop
-// spilled whole accumulators.
+// pass lists the skipped tiles of its column (its workgroups exit at once when there is none: the normal case for a
+// cell-sorted segment), stages just their steps and computes them with a per-pair gather from the table in global
+// memory, continuing the softmax in place from the fast pass's (O, LSE).
 //
 // Chaining: the keys of one softmax may be split between the region kernels (scattered keys) and this one.  With
 // (O_in, LSE_in) given, the online softmax starts from that state (m = LSE_in, l = 1, o = O_in) and the result is the
 // softmax over both segments; with O_in == NULL it starts empty.
+#include <type_traits>
 #include "attn_cell.h"
 
 namespace {
 
-constexpr float RESCALE_THR = 2.0f;   // log2 units; as attn_fwd.hip (also the slack of LSE plane 1)
+constexpr float MASS_THR = 4.0f;      // move the reference up when a tile's mass exceeds this: every weight <= 4 = 2^2
+constexpr float LOG2_MASS_THR = 2.0f; // ... which is also the slack of LSE plane 1 (as attn_fwd.hip's RESCALE_THR)
+constexpr float MASS_REDO = 1.0e18f;  // a tile this heavy (or inf / NaN) is redone with its exact maximum
 
 template <int PREC> struct LdsC {
   static constexpr int EB = Elem<PREC>::bytes;
@@ -33,12 +42,17 @@ template <int PREC> struct LdsC {
   static constexpr int KW_BYTES = KT * 16;
   static constexpr int WL = 8 * EB;                 // bytes of one lane's chunk operand
   static constexpr int W_BYTES = 2 * 64 * WL;       // two tiles per step
-  static constexpr int BUF = K_BYTES + V_BYTES + KW_BYTES + W_BYTES;
+  static constexpr int CT_BYTES = 2 * 16;           // two CellTile records
+  static constexpr int OFF_V = K_BYTES, OFF_KW = K_BYTES + V_BYTES, OFF_W = OFF_KW + KW_BYTES, OFF_CT = OFF_W + W_BYTES;
+  static constexpr int OFF_DUMMY = OFF_CT + CT_BYTES;   // 16 B that idle staging threads write (keeps staging branch-free)
+  static constexpr int BUF = OFF_DUMMY + 16;
   static constexpr int KCH_ROW = 32 * EB / 16;      // 16-B chunks per K row
   static constexpr int VCH_ROW = KT * EB / 16;      // 16-B chunks per V^T row of this step
   static constexpr int CH = KT * KCH_ROW;           // chunks per tile (K rows, V^T rows): 256 / 512
   static constexpr int NCH = 2 * CH + KT;           // + one KeyW record per key
   static constexpr int NST = PREC == BEVR_PREC_BF16 ? 2 : 3;   // chunks a thread carries in registers across a step
+  static constexpr int QCH = 32 * EB / 16 / 2;      // 16-B chunks of one lane's Q fragment: 2 (bf16) / 4 (f32)
+  static constexpr int QSLOT = QCH * 1024;          // per wave: [chunk][lane] -- consecutive lanes, consecutive 16 B
 };
 
 // staging chunk g of a step: source at step 0, byte increment per step, LDS destination inside a buffer
@@ -55,12 +69,12 @@ __device__ __forceinline__ void chunk_map(int g, const char* Kh, const char* Vh,
     const int ci = g - L::CH;
     src = Vh + ((size_t)(ci / L::VCH_ROW) * Np) * EB + (ci % L::VCH_ROW) * 16;
     inc = KT * EB;
-    dst = L::K_BYTES + (ci / L::VCH_ROW) * L::V_STRIDE + (ci % L::VCH_ROW) * 16;
+    dst = L::OFF_V + (ci / L::VCH_ROW) * L::V_STRIDE + (ci % L::VCH_ROW) * 16;
   } else {
     const int ci = g - 2 * L::CH;
     src = kws + (size_t)ci * 16;
     inc = KT * 16;
-    dst = L::K_BYTES + L::V_BYTES + ci * 16;
+    dst = L::OFF_KW + ci * 16;
   }
 }
 
@@ -71,7 +85,8 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     const float* __restrict__ LSE_in, float* __restrict__ O, float* __restrict__ LSE) {
   typedef LdsC<PREC> L;
   constexpr int EB = L::EB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 staging buffers + one Q fragment slot per wave
+  // 2 staging buffers | one Q fragment slot per wave | (slow pass) the list of this column's slow tiles
+  extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int n_ph = d.n_prob * d.heads;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -99,38 +114,55 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
   const float jrx = (float)j * rx;
   const size_t mq = (size_t)j * d.Sp + i0 + lq;
   const int n_step = d.Np / KT;
-  if constexpr (SLOW) {   // anything for this column?  (uniform: scalar loads of the tile boxes)
-    bool any = false;
-    for (int u = 0; u < 2 * n_step; ++u) {
+
+  char* qslot = smem + 2 * L::BUF + wave * L::QSLOT + lane * 16;
+  int* slow_list = reinterpret_cast<int*>(smem + 2 * L::BUF + n_wave * L::QSLOT);
+  __shared__ int slow_count;
+  if constexpr (SLOW) {
+    // this column's slow tiles, listed in key order (the order of the list is the summation order: deterministic).
+    // One tile box per thread and round -> a flag byte; then wave 0 compacts the flags with ballots.
+    unsigned char* flag = reinterpret_cast<unsigned char*>(smem);   // the staging buffers are not in use yet
+    for (int u = tid; u < 2 * n_step; u += nt) {
       const CellTile c = make_celltile(kbox[u], jrx);
-      any = any || (c.live && !c.fast);
+      flag[u] = (c.live && !c.fast) ? 1 : 0;
     }
-    if (!any) return;
+    __syncthreads();
+    if (wave == 0) {
+      int cnt = 0;
+      for (int b0 = 0; b0 < 2 * n_step; b0 += 64) {
+        const bool f = b0 + lane < 2 * n_step && flag[b0 + lane];
+        const unsigned long long mask = __ballot(f);
+        if (f) slow_list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = b0 + lane;
+        cnt += __popcll(mask);
+      }
+      if (lane == 0) slow_count = cnt;
+    }
+    __syncthreads();
+    if (slow_count == 0) return;
   }
 
   // the Q fragment lives in LDS (own lanes' data, written and read by this wave only: no barrier) and is re-read per
   // tile: 8 (bf16) / 16 (f32) registers less to carry through the loop
-  char* qslot = smem + 2 * L::BUF + (wave * 64 + lane) * (32 * EB);
   {
     Frag<PREC> qf;
     qf.load(Qh + mq * 32 * EB, hi);
     if constexpr (PREC == BEVR_PREC_BF16) {
       *reinterpret_cast<u32x4*>(qslot) = __builtin_bit_cast(u32x4, qf.v[0]);
-      *reinterpret_cast<u32x4*>(qslot + 16) = __builtin_bit_cast(u32x4, qf.v[1]);
+      *reinterpret_cast<u32x4*>(qslot + 1024) = __builtin_bit_cast(u32x4, qf.v[1]);
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        *reinterpret_cast<f32x4*>(qslot + 16 * k) = f32x4{qf.v[4 * k], qf.v[4 * k + 1], qf.v[4 * k + 2], qf.v[4 * k + 3]};
+        *reinterpret_cast<f32x4*>(qslot + 1024 * k) = f32x4{qf.v[4 * k], qf.v[4 * k + 1], qf.v[4 * k + 2], qf.v[4 * k + 3]};
     }
   }
   auto load_q = [&](Frag<PREC>& f) {
     if constexpr (PREC == BEVR_PREC_BF16) {
       f.v[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qslot));
-      f.v[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qslot + 16));
+      f.v[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qslot + 1024));
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(qslot + 16 * k);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(qslot + 1024 * k);
         f.v[4 * k] = t[0]; f.v[4 * k + 1] = t[1]; f.v[4 * k + 2] = t[2]; f.v[4 * k + 3] = t[3];
       }
     }
@@ -139,13 +171,13 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
   // ---- online-softmax state --------------------------------------------------------------------------
   f32x16 o;
   float m = 0.f, l = 0.f;
-  bool first = true;   // the running max is not set yet (wave-uniform)
+  bool first = true;   // the reference m is not set yet (wave-uniform)
   if (O_in) {
     const float lse_in = LSE_in[(size_t)ph * Mp + mq];
-    // rows past the grid hold -inf in the incoming plane: start them empty (their results are never read)
+    // rows never written hold -inf in the incoming plane: start them from 0 (their results are never read)
     if (__any(lse_in > -3.0e38f)) {
       first = false;
-      m = fmaxf(lse_in, -1.0e30f);
+      m = lse_in > -3.0e38f ? lse_in : 0.f;
       l = hi == 0 ? 1.f : 0.f;       // the halves' denominators are added in the epilogue
       const float* orow = O_in + ((size_t)ph * Mp + mq) * 32;
 #pragma unroll
@@ -161,117 +193,39 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
   }
 
-  // ---- staging: global -> registers -> LDS, one step ahead ----------------------------------------------
-  u32x4 st[L::NST];
-  const char* st_src[L::NST];
-  int st_inc[L::NST], st_dst[L::NST];
-#pragma unroll
-  for (int k = 0; k < L::NST; ++k) {
-    const int g = tid + k * nt;
-    st_dst[k] = -1;
-    st_src[k] = Kh;
-    st_inc[k] = 0;
-    if (g < L::NCH) chunk_map<PREC>(g, Kh, Vh, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
-  }
-  auto stage_load = [&](int step) {
-#pragma unroll
-    for (int k = 0; k < L::NST; ++k)
-      if (st_dst[k] >= 0) st[k] = *reinterpret_cast<const u32x4*>(st_src[k] + (size_t)step * st_inc[k]);
-  };
-  auto stage_store = [&](int buf, int step) {
-    char* base = smem + buf * L::BUF;
-#pragma unroll
-    for (int k = 0; k < L::NST; ++k)
-      if (st_dst[k] >= 0) *reinterpret_cast<u32x4*>(base + st_dst[k]) = st[k];
-    // small workgroups (few row blocks): the chunks beyond the registers' share are copied through directly
-    for (int g = tid + L::NST * nt; g < L::NCH; g += nt) {
-      const char* src;
-      int inc, dst;
-      chunk_map<PREC>(g, Kh, Vh, kws, d.Np, src, inc, dst);
-      *reinterpret_cast<u32x4*>(base + dst) = *reinterpret_cast<const u32x4*>(src + (size_t)step * inc);
-    }
-  };
-  // the weights of tile `t` of step `step`, built by this wave (lane & 31 = key) into buffer `buf`
-  auto build_w = [&](int buf, int step, int t, const KeyW& kw) {
-    const StepBox sb = kbox[2 * step + t];
-    const CellTile ct = make_celltile(sb, jrx);
-    float tcol, trow;
-    cell_coords(kw, jrx, ct.x0, step * KT + t * 32 + lq >= d.N, tcol, trow);
-    const CellFrag<PREC> w = cell_weights<PREC>(tcol, trow, hi);
-    char* dst = smem + buf * L::BUF + L::K_BYTES + L::V_BYTES + L::KW_BYTES + (t * 64 + lane) * L::WL;
-    if constexpr (PREC == BEVR_PREC_BF16) {
-      *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, w.v);
-    } else {
-      *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
-      *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
-    }
-  };
-  auto load_kw = [&](int step, int t) {
-    return *reinterpret_cast<const KeyW*>(kws + ((size_t)step * KT + t * 32 + lq) * sizeof(KeyW));
-  };
-  // which wave builds tile t of a step: rotates, so that the extra work is spread evenly
-  auto builder_of = [&](int step, int t) { return (2 * step + t) % n_wave; };
-
-  stage_load(0);
-  stage_store(0, 0);
-  if constexpr (!SLOW) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (builder_of(0, t) == wave) build_w(0, 0, t, load_kw(0, t));
-  }
-  __syncthreads();
-
-  // table operand of the chunk this wave holds, and its origin
-  CellFrag<PREC> tf;
+  // ---- one tile: S^T = K Q^T (+ bias), P = exp2(S^T - m), l += sum P, o += V^T P^T -----------------------------
+  CellFrag<PREC> tf;          // table operand of the chunk this wave holds, and its origin
   int tag_x = 1 << 30, tag_a = 1 << 30;
   if constexpr (PREC == BEVR_PREC_BF16) tf.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) tf.v[k] = 0.f;
   }
-
-  for (int step = 0; step < n_step; ++step) {
-    const int buf = step & 1;
-    const char* base = smem + buf * L::BUF;
-    const bool more = step + 1 < n_step;
-    if (more) stage_load(step + 1);
-    // the next step's key records of the tiles this wave builds (global loads, consumed after this step's tiles)
-    KeyW kwn[2];
-    bool bld[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      bld[t] = !SLOW && more && builder_of(step + 1, t) == wave;
-      kwn[t] = KeyW{0, 0.f, 0.f, 0};
-      if (bld[t]) kwn[t] = load_kw(step + 1, t);
+  // MASKED: the tile may hold padded keys (last step only).  A separate instantiation: inside one body the compiler
+  // hoisted the 16 key-index compares out of the `last step` branch and every tile paid 32 instructions for them.
+  auto tile = [&](auto masked_tag, const char* base, int step, int t, int x0, int a0) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    if constexpr (!SLOW) {
+      if (x0 != tag_x || a0 != tag_a) {   // uniform: new chunk origin
+        tf = cell_table<PREC>(tbl, d, x0, a0 + i0 + lq, hi);
+        tag_x = x0;
+        tag_a = a0;
+      }
     }
-    const KeyW* kwl = reinterpret_cast<const KeyW*>(base + L::K_BYTES + L::V_BYTES);
-
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const StepBox sb = kbox[2 * step + t];
-      const CellTile ct = make_celltile(sb, jrx);
-      if (!ct.live || (bool)ct.fast == SLOW) continue;   // no unmasked key in this half / the other pass's tile (uniform)
-
-      Frag<PREC> kf, vf;
-      kf.load(base + (t * 32 + lq) * L::K_STRIDE, hi);
-      load_perm(vf, base + L::K_BYTES + lq * L::V_STRIDE + t * 32 * EB, hi);
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; ++attempt) {
       f32x16 s;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = -m;
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;   // literal-zero accumulator: no register splat
       {
-        Frag<PREC> qf;
+        Frag<PREC> kf, qf;
+        kf.load(base + (t * 32 + lq) * L::K_STRIDE, hi);
         load_q(qf);
-        s = mma_frag(kf, qf, s);   // S^T - m
+        s = mma_frag(kf, qf, s);   // S^T[key][query]
       }
-
       if constexpr (!SLOW) {
-        if (ct.x0 != tag_x || ct.a0 != tag_a) {   // uniform
-          tf = cell_table<PREC>(tbl, d, ct.x0, ct.a0 + i0 + lq, hi);
-          tag_x = ct.x0;
-          tag_a = ct.a0;
-        }
         CellFrag<PREC> wf;
-        const char* wsrc = base + L::K_BYTES + L::V_BYTES + L::KW_BYTES + (t * 64 + lane) * L::WL;
+        const char* wsrc = base + L::OFF_W + (t * 64 + lane) * L::WL;
         if constexpr (PREC == BEVR_PREC_BF16) {
           wf.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc));
         } else {
@@ -281,7 +235,8 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
         }
         s = mma_cell(wf, tf, s);   // + bias^T[key][query]
       } else {
-        // the tile's taps do not fit one chunk: per-pair gather from the table in global memory (any key set)
+        // per-pair gather from the table in global memory (any key set)
+        const KeyW* kwl = reinterpret_cast<const KeyW*>(base + L::OFF_KW);
         const int rowoff = (i0 + lq) * 8;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -296,48 +251,184 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
           const float u0 = t0[0] * wy0 + t0[1] * c.fy;
           const float u1 = t1[0] * wy0 + t1[1] * c.fy;
           s[r] += u0 + fx * (u1 - u0);
-          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight (rare path, register budget)
+          if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the loads in flight (register budget)
         }
       }
-      // mask padded keys (only the last step can hold any)
-      if (step == n_step - 1 && d.N < d.Np) {
+      if constexpr (MASKED) {   // padded keys: no weight
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = (step * KT + t * 32 + crow(r, hi) >= d.N) ? BEVR_NEG_BIG : s[r];
       }
-
-      // online softmax with a lazily updated running max: s holds S - m
-      float tm = s[0];
+      if (first || attempt == 1) {   // exact maximum of the tile: sets / moves the reference before the weights are formed
+        float tm = s[0];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
-      if (first || __any(tm > RESCALE_THR)) {   // wave-uniform: rare after the first tiles
-        tm = fmaxf(tm, __shfl_xor(tm, 32));     // the lane halves hold the same queries, different keys
-        const float up = first ? tm : fmaxf(tm, 0.f);
-        const float al = fast_exp2(-up);
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
+        tm = fmaxf(tm, __shfl_xor(tm, 32));   // the lane halves hold the same queries, different keys
+        const float mn = first ? tm : fmaxf(m, tm);
+        const float al = first ? 0.f : fast_exp2(m - mn);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[r] *= al; s[r] -= up; }
+        for (int r = 0; r < 16; ++r) o[r] *= al;
         l *= al;
-        m += up;
+        m = mn;
         first = false;
       }
+      const f32x2 nm = {-m, -m};
       f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const f32x2 pp = {fast_exp2(s[r]), fast_exp2(s[r + 1])};
+        const f32x2 sh = f32x2{s[r], s[r + 1]} + nm;
+        const f32x2 pp = {fast_exp2(sh[0]), fast_exp2(sh[1])};
         s[r] = pp[0];
         s[r + 1] = pp[1];
         ls2 += pp;
       }
-      l += ls2[0] + ls2[1];
-      o = mma_acc_b(vf, s, o);
-    }
-
-    if (more) {
+      const float ts = ls2[0] + ls2[1];
+      if (attempt == 0 && __any(!(ts <= MASS_REDO))) continue;   // overflowed against the old reference: redo exactly
+      l += ts;
+      {
+        Frag<PREC> vf;
+        load_perm(vf, base + L::OFF_V + lq * L::V_STRIDE + t * 32 * EB, hi);
+        o = mma_acc_b(vf, s, o);
+      }
+      if (__any(ts > MASS_THR)) {   // wave-uniform, rare: keep every committed weight <= MASS_THR of the reference
+        const float tb = ts + __shfl_xor(ts, 32);
+        const float up = fmaxf(ceilf(__log2f(tb)), 0.f);
+        const float al = fast_exp2(-up);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if (bld[t]) build_w(buf ^ 1, step + 1, t, kwn[t]);
-      stage_store(buf ^ 1, step + 1);
+        for (int r = 0; r < 16; ++r) o[r] *= al;
+        l *= al;
+        m += up;
+      }
+      break;
     }
+  };
+
+  // ---- staging helpers -------------------------------------------------------------------------------------
+  u32x4 st[L::NST];
+  const char* st_src[L::NST];
+  int st_inc[L::NST], st_dst[L::NST];
+#pragma unroll
+  for (int k = 0; k < L::NST; ++k) {
+    const int g = tid + k * nt;
+    // threads beyond the chunk count re-read chunk 0 into a dummy slot: loads and stores stay unconditional (a load
+    // under a branch feeding a loop-carried register is waited for on the spot)
+    chunk_map<PREC>(g < L::NCH ? g : 0, Kh, Vh, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
+    if (g >= L::NCH) st_dst[k] = L::OFF_DUMMY;
+  }
+  // copy a whole step through (small workgroups: the chunks beyond the registers' share; the slow pass: everything)
+  auto stage_direct = [&](char* base, int step, int g0) {
+    for (int g = g0; g < L::NCH; g += nt) {
+      const char* src;
+      int inc, dst;
+      chunk_map<PREC>(g, Kh, Vh, kws, d.Np, src, inc, dst);
+      *reinterpret_cast<u32x4*>(base + dst) = *reinterpret_cast<const u32x4*>(src + (size_t)step * inc);
+    }
+  };
+
+  if constexpr (SLOW) {
+    // ---- slow pass: only the listed tiles; their steps are staged on demand -----------------------------------
+    const int n_slow = slow_count;
+    for (int u = 0; u < n_slow; ++u) {
+      const int tile_id = slow_list[u];
+      const int step = tile_id >> 1, t = tile_id & 1;
+      __syncthreads();                  // every wave is done with the previous tile's buffer
+      stage_direct(smem, step, tid);
+      __syncthreads();
+      if (step == n_step - 1 && d.N < d.Np) tile(std::true_type{}, smem, step, t, 0, 0);
+      else tile(std::false_type{}, smem, step, t, 0, 0);
+    }
+  } else {
+    // ---- fast pass: pipelined over the steps --------------------------------------------------------------------
+    // weights and geometry of tile t of a step, by this wave (lane & 31 = key), into buffer `buf`
+    auto build_w = [&](int buf, int step, int t, const KeyW& kw, const StepBox& sb) {
+      const CellTile ct = make_celltile(sb, jrx);
+      float tcol, trow;
+      cell_coords(kw, jrx, ct.x0, step * KT + t * 32 + lq >= d.N, tcol, trow);
+      const CellFrag<PREC> w = cell_weights<PREC>(tcol, trow, hi);
+      char* bb = smem + buf * L::BUF;
+      char* dst = bb + L::OFF_W + (t * 64 + lane) * L::WL;
+      if constexpr (PREC == BEVR_PREC_BF16) {
+        *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, w.v);
+      } else {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
+        *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
+      }
+      if (lane == 0) *reinterpret_cast<CellTile*>(bb + L::OFF_CT + t * 16) = ct;
+    };
+    auto load_kw = [&](int step, int t) {
+      return *reinterpret_cast<const KeyW*>(kws + ((size_t)step * KT + t * 32 + lq) * sizeof(KeyW));
+    };
+    // which wave builds tile t of a step: rotates, so that the extra work is spread evenly
+    auto builder_of = [&](int step, int t) { return (2 * step + t) % n_wave; };
+
+#pragma unroll
+    for (int k = 0; k < L::NST; ++k)
+      *reinterpret_cast<u32x4*>(smem + st_dst[k]) = gload16(st_src[k]);
+    stage_direct(smem, 0, tid + L::NST * nt);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (builder_of(0, t) == wave) build_w(0, 0, t, load_kw(0, t), kbox[t]);
     __syncthreads();
+
+    StepBox sb_nxt[2] = {kbox[2 * min(1, n_step - 1)], kbox[2 * min(1, n_step - 1) + 1]};
+    // a last step with padded keys is peeled off behind the loop (its masked tile body inside the loop cost every tile
+    // registers or hoisted compares)
+    const int n_main = d.N < d.Np ? n_step - 1 : n_step;
+    for (int step = 0; step < n_main; ++step) {
+      const int buf = step & 1;
+      const char* base = smem + buf * L::BUF;
+      const bool more = step + 1 < n_step;
+      if (more) {
+#pragma unroll
+        for (int k = 0; k < L::NST; ++k) {
+          st_src[k] += st_inc[k];
+          st[k] = gload16(st_src[k]);
+        }
+      }
+      // the next step's key record for the tile this wave builds: loaded unconditionally (a load under a branch is
+      // waited for at the end of the branch, with every staging load in front of it: the builder wave then sat out a
+      // full memory latency per step and the workgroup waited for it at the barrier), consumed after the tiles.
+      // A wave builds at most one tile of a step (two only when it is the workgroup's only wave).
+      const int nstep_c = min(step + 1, n_step - 1);
+      const int tb = builder_of(step + 1, 1) == wave ? 1 : 0;
+      const bool bld = more && builder_of(step + 1, tb) == wave;
+      const KeyW kwn = load_kw(nstep_c, tb);
+      const StepBox sbb = sb_nxt[tb];
+      const StepBox sbo = sb_nxt[1 - tb];
+      sb_nxt[0] = kbox[2 * min(step + 2, n_step - 1)];
+      sb_nxt[1] = kbox[2 * min(step + 2, n_step - 1) + 1];
+
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        // the tile's geometry, computed once by the builder: one broadcast read instead of ~40 instructions per wave
+        const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);
+        const int live = __builtin_amdgcn_readfirstlane((int)cw[0]), fast = __builtin_amdgcn_readfirstlane((int)cw[1]);
+        if (!live || !fast) continue;   // nothing to do / the slow pass's tile (uniform)
+        tile(std::false_type{}, base, step, t, __builtin_amdgcn_readfirstlane((int)cw[2]),
+             __builtin_amdgcn_readfirstlane((int)cw[3]));
+      }
+
+      if (more) {
+        if (bld) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
+        if (n_wave == 1) build_w(buf ^ 1, step + 1, 1 - tb, load_kw(step + 1, 1 - tb), sbo);
+        char* nb = smem + (buf ^ 1) * L::BUF;
+#pragma unroll
+        for (int k = 0; k < L::NST; ++k)
+          *reinterpret_cast<u32x4*>(nb + st_dst[k]) = st[k];
+        stage_direct(nb, step + 1, tid + L::NST * nt);
+      }
+      __syncthreads();
+    }
+    if (n_main < n_step) {   // the peeled last step: padded keys masked
+      const char* base = smem + (n_main & 1) * L::BUF;
+#pragma unroll 1
+      for (int t = 0; t < 2; ++t) {
+        const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);
+        const int live = __builtin_amdgcn_readfirstlane((int)cw[0]), fast = __builtin_amdgcn_readfirstlane((int)cw[1]);
+        if (!live || !fast) continue;
+        tile(std::true_type{}, base, n_main, t, __builtin_amdgcn_readfirstlane((int)cw[2]),
+             __builtin_amdgcn_readfirstlane((int)cw[3]));
+      }
+    }
   }
 
   // ---- epilogue: normalise, store O^T tile as [q][32] rows and the log2-sum-exp planes -------------------
@@ -356,8 +447,8 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     }
     if (hi == 0) {
       Lh[mq] = m + __log2f(lt);
-      // plane 1: upper bound of log2 of the row's largest softmax weight (every logit <= m + RESCALE_THR)
-      Lh[(size_t)n_ph * Mp + mq] = RESCALE_THR - __log2f(lt);
+      // plane 1: upper bound of log2 of the row's largest softmax weight (every committed weight <= MASS_THR 2^m)
+      Lh[(size_t)n_ph * Mp + mq] = LOG2_MASS_THR - __log2f(lt);
     }
   }
 }
@@ -365,16 +456,19 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
 template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Vt, const void* key_ws,
            const float* table_pair, const float* O_in, const float* LSE_in, float* O, float* LSE, hipStream_t st) {
+  typedef LdsC<PREC> L;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * d.S;
   const int n_wave = d.Sp / 32;
-  const size_t lds = 2 * LdsC<PREC>::BUF + (size_t)n_wave * 64 * 32 * LdsC<PREC>::EB;
+  const size_t lds = 2 * L::BUF + (size_t)n_wave * L::QSLOT;
   hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
                      (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O_in, LSE_in, O, LSE);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  // slow pass, in place: continues from the fast pass's state
-  hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
+  // slow pass, in place: continues from the fast pass's state; its LDS also holds the list of slow tiles
+  const size_t lds_slow = lds + (size_t)(d.Np / 32) * 4;
+  if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
+  hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d, (const char*)Q,
                      (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, (const float*)O,
                      (const float*)LSE, O, LSE);
   return (int)hipGetLastError();

@@ -5,11 +5,17 @@ sample_3d_points).  The reference re-stacks and re-uploads the static reference 
 and syncs the host with `.item()`; here they are projected once per (module, device), cached on the
 device and broadcast over the batch as a view.
 """
+import os
+
+import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import ops
 from .SCA_deform_attn import SCADeformableAttention
+
+
+MIN_CELL_KEYS = int(os.environ.get("BEVR_CELL_MIN", "1024"))   # fewer pinned keys per view than this: not worth a second key segment
 
 
 def pillar_grid(bev_bound, S: int, D: int, z_shift: float) -> torch.Tensor:
@@ -62,31 +68,56 @@ class SpatialCrossAttn(nn.Module):
         """{vehicle_code: [ (2, S/2, S, D) per camera ]}, projected on the projector's device (lazy)."""
         return self.projector.bev_grid_to_camera(self.sample_3d_points())
 
-    def reference_points(self, vehicle_code: int, device) -> torch.Tensor:
-        """((V, S/2, S*D, 2) reference points in (x, y), (V, N) key order), cached per device."""
+    def reference_points(self, vehicle_code: int, device):
+        """((V, S/2, S*D, 2) reference points in (x, y), (V, N) static key order, cell_split), cached per device.
+
+        Key order of a view = [segment A | segment B]:
+          B, keys [cell_split, N): pillar points the camera does not see.  The projector pins them all to pixel (0, 0)
+             (reference model/bev_cmr_proj.py:76), so they differ only by their learned offsets and crowd ~70 cells of
+             the rpe table; SCADeformableAttention sorts them by cell per call and runs them through the cell kernels
+             (csrc/attn_cell.h).  Every view contributes the same number of them (the smallest pinned count over the
+             views, rounded down to a multiple of 64), so that both segments have one length for all problems.
+          A, keys [0, cell_split): the points the camera sees (+ the view's surplus pinned points), in the static k-d
+             order of their projections (ops.kd_key_order), through the region kernels.
+        Softmax attention is invariant to the order of its keys: the order and the split change no result."""
         key = (int(vehicle_code), str(device))
         if key not in self._ref_cache:
             pts = self.projector.bev_grid_to_camera(self.sample_3d_points(), device=device)[int(vehicle_code)]
             r = torch.stack(pts, 0)                                    # (V, 2, h, w, d)
             V, _, h, w, d = r.shape
             ref = r.permute(0, 2, 3, 4, 1).reshape(V, h, w * d, 2).contiguous()
-            # static k-d ordering of each view's keys by their projected position (ops.kd_key_order)
             S, D = self.bev_feat_shape, self.bev_depth_dim
-            yx = ref.reshape(V, -1, 2)[..., (1, 0)].double().cpu().numpy()
-            order = torch.stack([torch.from_numpy(ops.kd_key_order(yx[v], S, 2 * S * D - 1)) for v in range(V)], 0)
-            self._ref_cache[key] = (ref, order.to(device))
+            Wt = 2 * S * D - 1
+            yx_t = ref.reshape(V, -1, 2)[..., (1, 0)].double().cpu()
+            yx = yx_t.numpy()
+            N = yx.shape[1]
+            pinned = (yx_t == -1.0).all(-1)                            # (V, N): exactly pixel (0, 0)
+            n_b = (int(pinned.sum(1).min()) // 64) * 64
+            if n_b < MIN_CELL_KEYS or os.environ.get("BEVR_CELL", "1") == "0":
+                n_b = 0
+            orders = []
+            for v in range(V):
+                ip = torch.nonzero(pinned[v]).flatten().numpy()
+                seg_b = ip[len(ip) - n_b:] if n_b else ip[:0]
+                keep = np.ones(N, dtype=bool)
+                keep[seg_b] = False
+                seg_a = np.nonzero(keep)[0]
+                seg_a = seg_a[ops.kd_key_order(yx[v][seg_a], S, Wt)]
+                orders.append(torch.from_numpy(np.concatenate((seg_a, seg_b))))
+            order = torch.stack(orders, 0)
+            self._ref_cache[key] = (ref, order.to(device), N - n_b)
         return self._ref_cache[key]
 
     def forward(self, query, img_feat, vehicle_type_idx, wandb_log_dict, return_wandb_log=True):
         B = query.shape[0]
         code = int(vehicle_type_idx) if not torch.is_tensor(vehicle_type_idx) else self._code(vehicle_type_idx)
-        ref, order = self.reference_points(code, query.device)
+        ref, order, split = self.reference_points(code, query.device)
         ref = ref[None].expand(B, -1, -1, -1, -1)
         if img_feat.dim() == 4:
             img_feat = img_feat.reshape(B, self.num_views, *img_feat.shape[1:])
         return self.spatial_deform_attn(x=img_feat, query=query, reference_points=ref,
                                         wandb_log_dict=wandb_log_dict, return_wandb_log=return_wandb_log,
-                                        key_order=order)
+                                        key_order=order, cell_split=split)
 
     def _code(self, t: torch.Tensor) -> int:
         # One rig per model in the reference (VEHICLE_TYPE_CODE); avoid its per-call .item() sync when possible.

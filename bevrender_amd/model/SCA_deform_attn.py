@@ -99,10 +99,14 @@ class SCADeformableAttention(nn.Module):
             outs.append(pos.reshape(B, g, Hk * Wk, 2))
         return torch.stack(outs, 1)
 
-    def forward(self, x, query, reference_points, wandb_log_dict, return_wandb_log=True, key_order=None):
+    def forward(self, x, query, reference_points, wandb_log_dict, return_wandb_log=True, key_order=None,
+                cell_split=None):
         """x (B, V, C, Hi, Wi); query (B, C, S, S); reference_points (B, V, S/2, S*D, 2) in (x, y).
         key_order (V, N) long, optional: a per-view permutation of the keys (SpatialCrossAttn passes the static
-        k-d order of the camera projections); it changes no result, only the memory locality of the bias."""
+        k-d order of the camera projections); it changes no result, only the memory locality of the bias.
+        cell_split, optional: in that order the keys [cell_split, N) of every view are the ones the projector pinned to
+        pixel (0, 0); they are sorted by rpe-table cell here, per call (their learned offsets decide the cell), and
+        attended through the cell kernels (ops.attention_core).  Changes no result either."""
         B, V, C, Hi, Wi = x.shape
         S = query.shape[-1]
         if V != self.n_views:
@@ -113,13 +117,22 @@ class SCADeformableAttention(nn.Module):
         if key_order is not None:
             pos = pos.gather(3, key_order[None, :, None, :, None].expand(B, V, g, N, 2))
         pos = pos.reshape(B * V * g, N, 2)
+        if cell_split is not None and cell_split < N and g == 1:
+            # groups > 1: a key is one row of K built from all groups' samples, so the groups cannot be ordered
+            # independently; the split is simply not used then
+            with torch.no_grad():
+                a, b = ops.key_coords(pos[:, cell_split:], S, self.rpe_table.shape[-1], N - cell_split)
+                dyn = ops.cell_order(a, b)
+            pos = torch.cat((pos[:, :cell_split], pos[:, cell_split:].gather(1, dyn[..., None].expand(-1, -1, 2))), 1)
+        else:
+            cell_split = None
         xs = ops.sample_features(x.reshape(B * V, C, Hi, Wi), pos, g)            # (B*V, N, C)
         # proj_k and proj_v as ONE GEMM over the sampled features (same arithmetic per output column; the features are
         # read once instead of twice)
         kv = F.linear(xs, torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0),
                       torch.cat((self.proj_k.bias, self.proj_v.bias), 0))
         o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
-                               precision=self.precision, kv=kv)                  # (B*V, S*S, C)
+                               precision=self.precision, kv=kv, cell_split=cell_split)   # (B*V, S*S, C)
         o = o.reshape(B, V, S * S, C).permute(0, 2, 1, 3).reshape(B, S * S, V * C)
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
         return out.permute(0, 2, 1).reshape(B, C, S, S), wandb_log_dict

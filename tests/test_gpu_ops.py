@@ -454,7 +454,7 @@ def test_pack_kv_equals_the_stock_op_chain_and_unpack_is_its_adjoint(shape, prec
     L = _lib.lib()
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = L.bevr_pack_kv(p(kv), C.c_void_p(kv.data_ptr() + 4 * Cc), 2 * Cc, Bp, N, Np, h, c, prec, p(Kr), p(Vr), p(Kt),
+    rc = L.bevr_pack_kv(p(kv), C.c_void_p(kv.data_ptr() + 4 * Cc), 2 * Cc, N, Bp, N, Np, h, c, prec, p(Kr), p(Vr), p(Kt),
                         p(Vt), st)
     assert rc == 0
     k, v = kv[..., :Cc], kv[..., Cc:]
@@ -463,21 +463,40 @@ def test_pack_kv_equals_the_stock_op_chain_and_unpack_is_its_adjoint(shape, prec
     assert torch.equal(Kt, ops._perm_t(Kw)) and torch.equal(Vt, ops._perm_t(Vw))
     # no transposed outputs requested
     Kr2, Vr2 = torch.empty_like(Kr), torch.empty_like(Vr)
-    assert L.bevr_pack_kv(p(kv), C.c_void_p(kv.data_ptr() + 4 * Cc), 2 * Cc, Bp, N, Np, h, c, prec, p(Kr2), p(Vr2),
+    assert L.bevr_pack_kv(p(kv), C.c_void_p(kv.data_ptr() + 4 * Cc), 2 * Cc, N, Bp, N, Np, h, c, prec, p(Kr2), p(Vr2),
                           None, None, st) == 0
     assert torch.equal(Kr2, Kw) and torch.equal(Vr2, Vw)
     # adjoint on float gradients
     dK = torch.randn(Bp, h, Np, 32, generator=g).to(DEV)
     dV = torch.randn(Bp, h, Np, 32, generator=g).to(DEV)
     dkv = torch.full((Bp, N, 2 * Cc), 7.0, device=DEV)
-    assert L.bevr_unpack_dkv(p(dK), p(dV), p(dkv), C.c_void_p(dkv.data_ptr() + 4 * Cc), 2 * Cc, Bp, N, Np, h, c, st) == 0
+    assert L.bevr_unpack_dkv(p(dK), p(dV), p(dkv), C.c_void_p(dkv.data_ptr() + 4 * Cc), 2 * Cc, N, Bp, N, Np, h, c, st) == 0
     want_k = dK[:, :, :N, :c].permute(0, 2, 1, 3).reshape(Bp, N, Cc)
     want_v = dV[:, :, :N, :c].permute(0, 2, 1, 3).reshape(Bp, N, Cc)
     assert torch.equal(dkv[..., :Cc], want_k) and torch.equal(dkv[..., Cc:], want_v)
+    # a key SEGMENT of the rows (problem stride N rows, first row n0): what ops._AttnCore packs for each of its two
+    # key segments without copying them out
+    n0 = N // 3
+    Ns = N - n0
+    Nsp = 64 * ((Ns + 63) // 64)
+    Ks = torch.full((Bp, h, Nsp, 32), 7.0, device=DEV, dtype=ed)
+    Vs = torch.full_like(Ks, 7.0)
+    base = kv.data_ptr() + n0 * 2 * Cc * 4
+    assert L.bevr_pack_kv(C.c_void_p(base), C.c_void_p(base + 4 * Cc), 2 * Cc, N, Bp, Ns, Nsp, h, c, prec, p(Ks), p(Vs),
+                          None, None, st) == 0
+    seg = kv[:, n0:].contiguous()
+    assert torch.equal(Ks, ops.pack_keys(seg[..., :Cc], h).to(ed)) and torch.equal(Vs, ops.pack_keys(seg[..., Cc:], h).to(ed))
+    dks = torch.full((Bp, N, 2 * Cc), 7.0, device=DEV)
+    dKs, dVs = torch.randn(Bp, h, Nsp, 32, generator=g).to(DEV), torch.randn(Bp, h, Nsp, 32, generator=g).to(DEV)
+    sb = dks.data_ptr() + n0 * 2 * Cc * 4
+    assert L.bevr_unpack_dkv(p(dKs), p(dVs), C.c_void_p(sb), C.c_void_p(sb + 4 * Cc), 2 * Cc, N, Bp, Ns, Nsp, h, c, st) == 0
+    assert torch.equal(dks[:, n0:, :Cc], dKs[:, :, :Ns, :c].permute(0, 2, 1, 3).reshape(Bp, Ns, Cc))
+    assert (dks[:, :n0] == 7.0).all()                       # rows outside the segment untouched
     # argument contract
-    assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, Bp, N, Np + 1, h, c, prec, p(Kr), p(Vr), None, None, st) == -2
-    assert L.bevr_pack_kv(None, p(kv), 2 * Cc, Bp, N, Np, h, c, prec, p(Kr), p(Vr), None, None, st) == -1
-    assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, Bp, N, Np, h, c, 5, p(Kr), p(Vr), None, None, st) == -3
+    assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, N, Bp, N, Np + 1, h, c, prec, p(Kr), p(Vr), None, None, st) == -2
+    assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, N - 1, Bp, N, Np, h, c, prec, p(Kr), p(Vr), None, None, st) == -2   # problem stride < N
+    assert L.bevr_pack_kv(None, p(kv), 2 * Cc, N, Bp, N, Np, h, c, prec, p(Kr), p(Vr), None, None, st) == -1
+    assert L.bevr_pack_kv(p(kv), p(kv), 2 * Cc, N, Bp, N, Np, h, c, 5, p(Kr), p(Vr), None, None, st) == -3
 
 
 @pytest.mark.gpu

@@ -9,9 +9,11 @@ import json
 import re
 import sys
 
-root, batch, cmd = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+root, batch, cmd, sha = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
 NAMES = {"attn_fwd_kernel": "bevr_attn_fwd", "attn_bwd_q_kernel": "bevr_attn_bwd_q", "attn_bwd_k_win_kernel": "bevr_attn_bwd_k",
-         "attn_bwd_k_gather_kernel": "bevr_attn_bwd_k", "sample_fwd_kernel": "bevr_sample_fwd", "sample_bwd_kernel": "bevr_sample_bwd"}
+         "attn_bwd_k_gather_kernel": "bevr_attn_bwd_k", "sample_fwd_kernel": "bevr_sample_fwd", "sample_bwd_kernel": "bevr_sample_bwd",
+         "attn_cell_fwd_kernel": "bevr_attn_cell_fwd", "attn_cell_bwd_q_kernel": "bevr_attn_cell_bwd_q",
+         "attn_cell_bwd_k_kernel": "bevr_attn_cell_bwd_k"}
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(int))
 for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -24,13 +26,15 @@ for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
                 continue
             k = NAMES[m.group(1)]
             acc[k][counter] += float(r["Counter_Value"]) * 1024.0
-            if "gather" not in m.group(1):
+            # one entry point = one launch: the gather kernel rides with the window kernel, a cell kernel's slow pass
+            # (template argument true) with its fast pass
+            if "gather" not in m.group(1) and not re.search(r"attn_cell_\w+_kernel<\d+, true>", r["Kernel_Name"]):
                 launches[k][counter] += 1
 out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `" + cmd + "`; bytes summed over the "
                    "launches of the timed AND warm-up step, averaged per launch (bwd_k = window + gather kernels of one call). "
                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B read requests at 64 B); WRITE_SIZE as "
                    "read (float atomics and 16-B stores count exactly).",
-       "batch": batch, "bev": 200, "precision": "bf16", "kernels": {}}
+       "batch": batch, "bev": 200, "precision": "bf16", "csrc_sha": sha, "kernels": {}}
 for k in sorted(acc):
     n = max(launches[k]["FETCH_SIZE"], 1)
     f = 2.0 * acc[k]["FETCH_SIZE"] / n

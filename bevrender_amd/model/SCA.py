@@ -7,7 +7,6 @@ device and broadcast over the batch as a view.
 """
 import os
 
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -87,25 +86,9 @@ class SpatialCrossAttn(nn.Module):
             V, _, h, w, d = r.shape
             ref = r.permute(0, 2, 3, 4, 1).reshape(V, h, w * d, 2).contiguous()
             S, D = self.bev_feat_shape, self.bev_depth_dim
-            Wt = 2 * S * D - 1
-            yx_t = ref.reshape(V, -1, 2)[..., (1, 0)].double().cpu()
-            yx = yx_t.numpy()
-            N = yx.shape[1]
-            pinned = (yx_t == -1.0).all(-1)                            # (V, N): exactly pixel (0, 0)
-            n_b = (int(pinned.sum(1).min()) // 64) * 64
-            if n_b < MIN_CELL_KEYS or os.environ.get("BEVR_CELL", "1") == "0":
-                n_b = 0
-            orders = []
-            for v in range(V):
-                ip = torch.nonzero(pinned[v]).flatten().numpy()
-                seg_b = ip[len(ip) - n_b:] if n_b else ip[:0]
-                keep = np.ones(N, dtype=bool)
-                keep[seg_b] = False
-                seg_a = np.nonzero(keep)[0]
-                seg_a = seg_a[ops.kd_key_order(yx[v][seg_a], S, Wt)]
-                orders.append(torch.from_numpy(np.concatenate((seg_a, seg_b))))
-            order = torch.stack(orders, 0)
-            self._ref_cache[key] = (ref, order.to(device), N - n_b)
+            yx = ref.reshape(V, -1, 2)[..., (1, 0)].double().cpu().numpy()
+            order, split = ops.split_key_order(yx, S, 2 * S * D - 1, MIN_CELL_KEYS)
+            self._ref_cache[key] = (ref, order.to(device), split)
         return self._ref_cache[key]
 
     def forward(self, query, img_feat, vehicle_type_idx, wandb_log_dict, return_wandb_log=True):

@@ -166,6 +166,36 @@ def kd_key_order(pos_ref, S: int, Wt: int, leaf: int = 32):
     return np.concatenate(out)
 
 
+def split_key_order(ref_yx, S: int, Wt: int, min_cell_keys: int = 1024):
+    """Static key order of an SCA call with the projector's pinned keys split off: (order (V, N) int64 tensor, split).
+
+    ref_yx (V, N, 2) STATIC reference positions (y, x) of each view's keys.  Keys whose reference is exactly (-1, -1)
+    are the pillar points the camera does not see (the projector pins them to pixel (0, 0), reference
+    model/bev_cmr_proj.py:76): they differ only by their learned offsets and crowd ~70 cells of the rpe table.  Every
+    view sends the same number of them -- the smallest pinned count over the views, rounded down to a multiple of 64
+    -- to the END of its order, keys [split, N): the cell segment (sorted by table cell per call, cell_order, and
+    attended through the cell kernels).  Keys [0, split): everything else, in the k-d order of kd_key_order (the region
+    kernels).  Fewer than min_cell_keys pinned keys per view, or BEVR_CELL=0: split = N (no cell segment).
+    Softmax attention is invariant to the order of its keys: neither the order nor the split changes a result."""
+    import numpy as np
+    yx = np.asarray(ref_yx, dtype=np.float64)
+    V, N, _ = yx.shape
+    pinned = (yx == -1.0).all(-1)
+    n_b = (int(pinned.sum(1).min()) // 64) * 64
+    if n_b < min_cell_keys or os.environ.get("BEVR_CELL", "1") == "0":
+        n_b = 0
+    orders = []
+    for v in range(V):
+        ip = np.nonzero(pinned[v])[0]
+        seg_b = ip[len(ip) - n_b:] if n_b else ip[:0]
+        keep = np.ones(N, dtype=bool)
+        keep[seg_b] = False
+        seg_a = np.nonzero(keep)[0]
+        seg_a = seg_a[kd_key_order(yx[v][seg_a], S, Wt)]
+        orders.append(torch.from_numpy(np.concatenate((seg_a, seg_b))))
+    return torch.stack(orders, 0), N - n_b
+
+
 # --------------------------------------------------------------------------------------------------
 # kernel launchers
 # --------------------------------------------------------------------------------------------------

@@ -173,8 +173,11 @@ def tsa_key_positions(p: Dict[str, Tensor], query: Tensor, n_groups: int, kernel
 
 def tsa_forward(p: Dict[str, Tensor], query: Tensor, prev_bev: Optional[Tensor], *, n_heads: int,
                 n_groups: int = 1, kernel_size: int = 3, stride: int = 1,
-                scale_offset_range: bool = True) -> Tensor:
-    """TSADeformableAttention.forward(x=prev_bev, query).  `p` uses the reference's state_dict names."""
+                scale_offset_range: bool = True, rows: Optional[Tensor] = None) -> Tensor:
+    """TSADeformableAttention.forward(x=prev_bev, query).  `p` uses the reference's state_dict names.
+    rows (long tensor of query indices m = i*W + j, optional): evaluate the module's output at those BEV positions only
+    (attention rows and the 1x1 proj_out are independent per position) and return (B, C, len(rows)): how the module is
+    checked at sizes whose (M x N) tensors do not fit in host memory."""
     x = query.clone() if prev_bev is None else prev_bev                      # :142-143
     B, C, H, W = x.shape
     h, g = n_heads, n_groups
@@ -187,7 +190,9 @@ def tsa_forward(p: Dict[str, Tensor], query: Tensor, prev_bev: Optional[Tensor],
     q = query.reshape(B * h, c, H * W)                                        # :220 (raw query, proj_q unused)
     k = F.conv2d(xs, p["proj_k.weight"], p["proj_k.bias"]).reshape(B * h, c, N)
     v = F.conv2d(xs, p["proj_v.weight"], p["proj_v.bias"]).reshape(B * h, c, N)
-    out = attention_core(q, k, v, pos.reshape(B * g, N, 2), p["rpe_table"], H, W, g, c ** -0.5)
+    out = attention_core(q, k, v, pos.reshape(B * g, N, 2), p["rpe_table"], H, W, g, c ** -0.5, rows=rows)
+    if rows is not None:
+        return F.conv1d(out.reshape(B, C, len(rows)), p["proj_out.weight"].flatten(2), p["proj_out.bias"])
     out = out.reshape(B, C, H, W)
     return F.conv2d(out, p["proj_out.weight"], p["proj_out.bias"])            # :336
 
@@ -219,8 +224,10 @@ def sca_key_positions(p: Dict[str, Tensor], query: Tensor, ref_view: Tensor, vie
 
 
 def sca_forward(p: Dict[str, Tensor], x: Tensor, query: Tensor, reference_points: Tensor, *, n_heads: int,
-                n_groups: int = 1, depth_dim: int = 5, scale_offset_range: bool = True) -> Tensor:
-    """SCADeformableAttention.forward.  x (B, V, C, Hi, Wi); reference_points (B, V, S/2, S*D, 2) in (x, y)."""
+                n_groups: int = 1, depth_dim: int = 5, scale_offset_range: bool = True,
+                rows: Optional[Tensor] = None) -> Tensor:
+    """SCADeformableAttention.forward.  x (B, V, C, Hi, Wi); reference_points (B, V, S/2, S*D, 2) in (x, y).
+    rows: as tsa_forward -- the output at the selected BEV positions only, (B, C, len(rows))."""
     B, V, C, Hi, Wi = x.shape
     S = query.shape[-1]
     h, g = n_heads, n_groups
@@ -237,9 +244,11 @@ def sca_forward(p: Dict[str, Tensor], x: Tensor, query: Tensor, reference_points
         q = query.reshape(B * h, c, S * S)                                    # :304-306
         k = F.conv2d(xs, p["proj_k.weight"], p["proj_k.bias"]).reshape(B * h, c, N)
         v = F.conv2d(xs, p["proj_v.weight"], p["proj_v.bias"]).reshape(B * h, c, N)
-        o = attention_core(q, k, v, pos.reshape(B * g, N, 2), p["rpe_table"], S, S, g, c ** -0.5)
-        outs.append(o.reshape(B, C, S, S))
+        o = attention_core(q, k, v, pos.reshape(B * g, N, 2), p["rpe_table"], S, S, g, c ** -0.5, rows=rows)
+        outs.append(o.reshape(B, C, S, S) if rows is None else o.reshape(B, C, len(rows)))
     out = torch.cat(outs, dim=1)                                              # "b v c h w -> b (v c) h w"
+    if rows is not None:
+        return F.conv1d(out, p["proj_out.weight"].flatten(2), p["proj_out.bias"])
     return F.conv2d(out, p["proj_out.weight"], p["proj_out.bias"])            # :415-420
 
 

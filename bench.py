@@ -30,7 +30,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md chip-level parameters
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md chip-level parameters
 HBM_PEAK_GBS = 8000.0
 N_CU, CLOCK_HZ = 256, 2.4e9                          # for the LDS-pipe view (roofline_lds)
 
@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--f32-steps", type=int, default=1,
                     help="also time this many steps in the exact-f32 MFMA mode (rank 0, N=1; 0 = skip)")
     ap.add_argument("--bev", type=int, default=200, help="BEV side (200 = BASELINE config; smaller for debugging)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

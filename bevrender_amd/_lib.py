@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVRENDER_LIB") or os.path.join(_HERE, "lib", "libbevrender_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 ABI_VERSION = 3   # BEVR_ABI_VERSION of include/bevrender_hip.h this binding was written against
 
 # every symbol include/bevrender_hip.h declares (checked by tests/test_capi_symbols.py)
@@ -82,10 +82,10 @@ def lib() -> C.CDLL:
         L.bevr_attn_key_prep.argtypes = [dp, fp, fp, vp, vp]
         L.bevr_attn_fwd.argtypes = [dp, vp, vp, vp, vp, fp, fp, fp, vp]
         L.bevr_attn_bwd_q.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, fp, fp, fp, fp, fp, vp]
-        L.bevr_attn_bwd_k.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, vp, fp, fp] + [fp] * 4 + [vp]
+        L.bevr_attn_bwd_k.argtypes = [dp] + [vp] * 4 + [fp] * 3 + [vp, vp, fp, fp, fp] + [fp] * 4 + [vp]
         L.bevr_attn_cell_fwd.argtypes = [dp, vp, vp, vp, vp, fp, fp, fp, fp, fp, vp]
-        L.bevr_attn_cell_bwd_q.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, fp, fp, fp, fp, vp]
-        L.bevr_attn_cell_bwd_k.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, vp, fp, fp] + [fp] * 4 + [vp]
+        L.bevr_attn_cell_bwd_q.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, fp, fp, fp, fp, fp, vp]
+        L.bevr_attn_cell_bwd_k.argtypes = [dp] + [vp] * 4 + [vp, fp] + [vp, vp, fp, fp, fp] + [fp] * 4 + [vp]
         L.bevr_sample_fwd.argtypes = [fp, fp, fp] + [ip] * 5 + [vp]
         L.bevr_sample_bwd.argtypes = [fp] * 5 + [ip] * 5 + [vp]
         L.bevr_project_bev_grid.argtypes = [fp] * 4 + [ip] * 4 + [vp]

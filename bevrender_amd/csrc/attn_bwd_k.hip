@@ -135,14 +135,17 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ Qt, const char* __restrict__ K,
     const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const char* __restrict__ dOt,
-    const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV,
-    float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
+    const float* __restrict__ LSE, const float* __restrict__ delta, const float* __restrict__ grad_scale,
+    float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
   // NT 32-query tiles are staged and processed per barrier.  With one tile per barrier the three waves of a SIMD
   // ran in lockstep -- MFMAs together, then the VALU-bound bias / exp / gradient loop together, then the barrier --
   // and each pipe idled while the other worked; with two, the waves drift apart inside an iteration and one wave's
   // MFMAs overlap another's VALU phase, and there are half as many barriers.  (f32 mode keeps one: its tiles are
   // twice the bytes and the LDS ring leaves no room.)
-  constexpr int NT = PREC == BEVR_PREC_BF16 ? 2 : 1;
+  constexpr int NT = is16(PREC) ? 2 : 1;
+  // fp16 mode (include/bevrender_hip.h, grad_scale[2..5]): P' = P 2^kp, dS16 = P' (dP - delta) c2
+  const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
+  const float ds_inv = PREC == BEVR_PREC_F16 ? grad_scale[4] : 1.f, p_inv = PREC == BEVR_PREC_F16 ? grad_scale[5] : 1.f;
   typedef LdsK<PREC, NT> L;
   constexpr int EB = L::EB;
   static_assert(2 * L::BUF + L::WCAP * 4 + 256 <= 160 * 1024, "LDS budget");
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
   QStage<PREC, TW, NT> qs;
   qs.init(tid, Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB, dO + ((size_t)ph * Mp) * 32 * EB,
           Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB, dOt + ((size_t)ph * 32) * Mp * EB,
-          LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp);
+          LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp, kp16);
   // tile t = (BEV column j = t / n_rb, row block rb = t % n_rb) is the 32 packed queries [32 t, 32 t + 32): consecutive
   // tiles are contiguous in memory.  Iteration `it` stages the NT tiles from first_tile(it); when the tile count is odd
   // the last iteration re-stages the previous tile in front of the last one (never reads past the array) and skips it.
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
           const f32x2 s2 = {s[r], s[r + 1]}, dp2 = {dp[r], dp[r + 1]};
           const f32x2 sv = (s2 + u0) + fx2 * du;
           const f32x2 pp = {fast_exp2(sv[0]), fast_exp2(sv[1])};   // padded keys: -1e30 from the kill column => 0
-          const f32x2 ds = pp * dp2;                               // ln2 folded into the epilogue
+          f32x2 ds = pp * dp2;                                     // ln2 folded into the epilogue
+          if constexpr (PREC == BEVR_PREC_F16) ds *= f32x2{c2_16, c2_16};
           s[r] = pp[0]; s[r + 1] = pp[1];
           dp[r] = ds[0]; dp[r + 1] = ds[1];
           const f32x2 d0 = tb - ta, d1 = qb - qa;
@@ -469,12 +473,12 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 a, b;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { a[k] = BEVR_LN2 * dk[w][4 * g4 + k]; b[k] = dv[w][4 * g4 + k]; }
+      for (int k = 0; k < 4; ++k) { a[k] = BEVR_LN2 * ds_inv * dk[w][4 * g4 + k]; b[k] = p_inv * dv[w][4 * g4 + k]; }
       *reinterpret_cast<f32x4*>(kr + 8 * g4 + 4 * hi) = a;
       *reinterpret_cast<f32x4*>(vr + 8 * g4 + 4 * hi) = b;
     }
-    const float sa = BEVR_LN2 * (da[w] + __shfl_xor(da[w], 32));
-    const float sb = BEVR_LN2 * (db[w] + __shfl_xor(db[w], 32));
+    const float sa = BEVR_LN2 * ds_inv * (da[w] + __shfl_xor(da[w], 32));
+    const float sb = BEVR_LN2 * ds_inv * (db[w] + __shfl_xor(db[w], 32));
     if (hi == 0) {
       atomicAdd(dkey_a + (size_t)(prob * d.groups + grp) * d.Np + key[w], sa);
       atomicAdd(dkey_b + (size_t)(prob * d.groups + grp) * d.Np + key[w], sb);
@@ -494,9 +498,11 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ Qt, const char* __restrict__ K,
     const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const char* __restrict__ dOt,
-    const float* __restrict__ LSE, const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV,
-    float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
+    const float* __restrict__ LSE, const float* __restrict__ delta, const float* __restrict__ grad_scale,
+    float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
   typedef LdsK<PREC> L;
+  const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
+  const float ds_inv = PREC == BEVR_PREC_F16 ? grad_scale[4] : 1.f, p_inv = PREC == BEVR_PREC_F16 ? grad_scale[5] : 1.f;
   constexpr int EB = L::EB;
   __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
   __shared__ __attribute__((aligned(16))) KBox red[4];
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
   QStage<PREC, TG> qs;
   qs.init(tid, Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB, dO + ((size_t)ph * Mp) * 32 * EB,
           Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB, dOt + ((size_t)ph * 32) * Mp * EB,
-          LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp);
+          LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp, kp16);
   const int n_all = d.S * n_rb;
   const int chunk = (n_all + GSPLIT - 1) / GSPLIT;
   const int it_first = split * chunk, n_it = min(n_all, it_first + chunk);
@@ -628,7 +634,7 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
         float u1 = t1[0] * c.wy0 + t1[1] * c.fy;
         float sv = s[r] + u0 + fx * (u1 - u0);
         float p = dead ? 0.f : fast_exp2(sv);
-        float ds = BEVR_LN2 * p * dp[r];
+        float ds = BEVR_LN2 * c2_16 * p * dp[r];
         s[r] = p;
         dp[r] = ds;
         float ga = (t0[1] - t0[0]) + fx * ((t1[1] - t1[0]) - (t0[1] - t0[0]));  // d bias / d a
@@ -656,12 +662,12 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
     for (int g4 = 0; g4 < 4; ++g4) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {   // partial sums of this workgroup's share of the sweep (rows cleared by the window kernel)
-        atomicAdd(kr + 8 * g4 + 4 * hi + k, dk[w][4 * g4 + k]);
-        atomicAdd(vr + 8 * g4 + 4 * hi + k, dv[w][4 * g4 + k]);
+        atomicAdd(kr + 8 * g4 + 4 * hi + k, ds_inv * dk[w][4 * g4 + k]);
+        atomicAdd(vr + 8 * g4 + 4 * hi + k, p_inv * dv[w][4 * g4 + k]);
       }
     }
-    float sa = da[w] + __shfl_xor(da[w], 32);
-    float sb = db[w] + __shfl_xor(db[w], 32);
+    float sa = ds_inv * (da[w] + __shfl_xor(da[w], 32));
+    float sb = ds_inv * (db[w] + __shfl_xor(db[w], 32));
     if (hi == 0) {
       atomicAdd(dkey_a + (size_t)(prob * d.groups + grp) * d.Np + key, sa);
       atomicAdd(dkey_b + (size_t)(prob * d.groups + grp) * d.Np + key, sb);
@@ -672,18 +678,18 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
 template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K, const void* V, const float* key_a,
            const float* key_b, const float* table_pair, const void* dO, const void* dOt, const float* LSE,
-           const float* delta, float* dK, float* dV, float* dka, float* dkb, hipStream_t st) {
+           const float* delta, const float* gs, float* dK, float* dV, float* dka, float* dkb, hipStream_t st) {
   const int n_kb = (d.Np + KEYS_WG - 1) / KEYS_WG;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_kb;
   hipLaunchKernelGGL((attn_bwd_k_win_kernel<PREC>), dim3(grid), dim3(TW), 0, st, d, (const char*)Q, (const char*)Qt,
                      (const char*)K, (const char*)V, key_a, key_b, (const char*)table_pair, (const char*)dO,
-                     (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
+                     (const char*)dOt, LSE, delta, gs, dK, dV, dka, dkb);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL((attn_bwd_k_gather_kernel<PREC>), dim3(grid * GSPLIT), dim3(TG), 0, st, d, (const char*)Q,
                      (const char*)Qt, (const char*)K, (const char*)V, key_a, key_b, (const char*)table_pair,
-                     (const char*)dO, (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
+                     (const char*)dO, (const char*)dOt, LSE, delta, gs, dK, dV, dka, dkb);
   return (int)hipGetLastError();
 }
 
@@ -691,20 +697,23 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K
 
 extern "C" int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
                                const float* key_a, const float* key_b, const float* table_pair, const void* dO,
-                               const void* dOt, const float* LSE, const float* delta, float* dK, float* dV,
-                               float* dkey_a, float* dkey_b, void* stream) {
+                               const void* dOt, const float* LSE, const float* delta, const float* grad_scale,
+                               float* dK, float* dV, float* dkey_a, float* dkey_b, void* stream) {
   int rc = bevr_check_desc(d);
   if (rc) return rc;
   if (!Q || !Qt || !K || !V || !key_a || !key_b || !table_pair || !dO || !dOt || !LSE || !delta || !dK || !dV ||
-      !dkey_a || !dkey_b)
+      !dkey_a || !dkey_b || (d->precision == BEVR_PREC_F16 && !grad_scale))
     return BEVR_E_NULL;
   if (!bevr_aligned16(Q) || !bevr_aligned16(Qt) || !bevr_aligned16(K) || !bevr_aligned16(V) || !bevr_aligned16(dO) ||
       !bevr_aligned16(dOt) || !bevr_aligned16(dK) || !bevr_aligned16(dV) || !bevr_aligned16(table_pair))
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
-    return launch<BEVR_PREC_BF16>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, dK, dV, dkey_a,
-                                  dkey_b, st);
-  return launch<BEVR_PREC_F32>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, dK, dV, dkey_a, dkey_b,
-                               st);
+    return launch<BEVR_PREC_BF16>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
+                                  dkey_a, dkey_b, st);
+  if (d->precision == BEVR_PREC_F16)
+    return launch<BEVR_PREC_F16>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
+                                 dkey_a, dkey_b, st);
+  return launch<BEVR_PREC_F32>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
+                               dkey_a, dkey_b, st);
 }

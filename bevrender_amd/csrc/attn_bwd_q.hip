@@ -59,13 +59,13 @@ template <int PREC> struct LdsQ {
   static constexpr int T_BYTES = 32 * T_STRIDE;
   static constexpr int C_BYTES = KT * 16 + 32;
   static constexpr int BUF = 2 * R_BYTES + T_BYTES + C_BYTES;
-  static constexpr int ENT = PREC == BEVR_PREC_BF16 ? 4 : 8;   // table-window entry: (T[y], T[y+1]) as bf16x2 / f32x2
+  static constexpr int ENT = is16(PREC) ? 4 : 8;   // table-window entry: (T[y], T[y+1]) as a 16-bit pair / f32x2
   static constexpr int WCOLS = CAP + 2;           // + two "kill" columns of -1e30: where masked keys point their taps
   static constexpr int WIN = WCOLS * WIN_PITCH * ENT;
   static constexpr int CELLS = CAP * WIN_PITCH;   // accumulation window: one 64-bit cell per table entry (+ kill columns)
-  static constexpr int PCK = NWAVE * 32 * (PREC == BEVR_PREC_BF16 ? 16 : 32);   // per wave: one 32-key half at a time
+  static constexpr int PCK = NWAVE * 32 * (is16(PREC) ? 16 : 32);   // per wave: one 32-key half at a time
   // bf16 mode: the tile's dO fragments live in LDS (fragment order, re-read every step) instead of 8 registers
-  static constexpr int QDO = PREC == BEVR_PREC_BF16 ? NCOL * 2 * 64 * 16 : 16;
+  static constexpr int QDO = is16(PREC) ? NCOL * 2 * 64 * 16 : 16;
   static constexpr int ACCB = 8;   // bytes per accumulation cell (see AccCell)
   static constexpr int TOTAL = BUF + WIN + WCOLS * WIN_PITCH * ACCB + PCK + QDO;
 };
@@ -111,7 +111,7 @@ struct AccCell {
 };
 
 template <int PREC>
-__global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q_kernel(
+__global__ __launch_bounds__(TQ, is16(PREC) ? 4 : 2) void attn_bwd_q_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Kt,
     const char* __restrict__ V, const char* __restrict__ key_ws,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const float* __restrict__ LSE,
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   constexpr int EB = L::EB;
   constexpr int CAP = L::CAP;
   constexpr int ENT = L::ENT;
-  static_assert(L::TOTAL <= (PREC == BEVR_PREC_BF16 ? 80 : 160) * 1024, "LDS budget");
+  static_assert(L::TOTAL <= (is16(PREC) ? 80 : 160) * 1024, "LDS budget");
   static_assert(NCOL == QCOLS, "group_width() assumes this tile width");
   // separate LDS objects: loads of the staged tiles / table window may be scheduled across the window atomics
   __shared__ __attribute__((aligned(16))) char smem[L::BUF];
@@ -175,6 +175,12 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   // folded into dO and delta when they are loaded, so P (dP - delta) comes out of the loop already in cell units;
   // the ln2 and 2^-e are applied once per flushed cell and once per dQ element.
   const float gscale = grad_scale[0], ginv = grad_scale[1] * BEVR_LN2;
+  // fp16 mode (include/bevrender_hip.h, grad_scale[2..5]): dO and delta are NOT scaled (2^30 / bound does not fit fp16);
+  // P' = P 2^kp and dS16 = P' (dP - delta) c2 stay inside fp16's normal range, the fixed-point cells count
+  // dS16 * cfix = dS * s, and dQ leaves in dS16 units
+  const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
+  const float cfix = PREC == BEVR_PREC_F16 ? grad_scale[0] * grad_scale[4] : 1.f;
+  const float dq_scale = PREC == BEVR_PREC_F16 ? grad_scale[4] * BEVR_LN2 : ginv;
 
   // this wave's query column; this lane's query row.  Lanes 0..30 of each half carry the tile's 31 queries, lane 31
   // none: its slot is the 32nd table row the tile's taps reach (query 30's lower tap), which lets every lane add the
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   const float lse = LSE[(size_t)ph * Mp + mq];
   float dlt = delta[(size_t)ph * Mp + mq];
   if (!live) {
-    if constexpr (PREC == BEVR_PREC_BF16) {
+    if constexpr (is16(PREC)) {
       dof.v[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
       dof.v[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     } else {
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
     }
     dlt = 0.f;
   }
-  dlt *= gscale;
+  if constexpr (PREC != BEVR_PREC_F16) dlt *= gscale;
   if constexpr (PREC == BEVR_PREC_BF16) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -213,11 +219,11 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
                            __builtin_bit_cast(float, w[k] & 0xffff0000u) * gscale);
       dof.v[h] = __builtin_bit_cast(bf16x8, w);
     }
-  } else {
+  } else if constexpr (PREC == BEVR_PREC_F32) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) dof.v[k] *= gscale;
   }
-  if constexpr (PREC == BEVR_PREC_BF16) {   // own lanes' data, written and read by this wave only
+  if constexpr (is16(PREC)) {   // own lanes' data, written and read by this wave only
     u32x4* qd = reinterpret_cast<u32x4*>(qdo) + col * 2 * 64 + lane;
     qd[0] = __builtin_bit_cast(u32x4, dof.v[0]);
     qd[64] = __builtin_bit_cast(u32x4, dof.v[1]);
@@ -287,8 +293,8 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
   // starts clean.
   for (int c = tid; c < L::WCOLS * WIN_PITCH; c += TQ) accw[c] = 0;
   if (tid < 2 * WIN_PITCH) {
-    if constexpr (PREC == BEVR_PREC_BF16)
-      *reinterpret_cast<unsigned*>(win + (CAP * WIN_PITCH + tid) * ENT) = pack_bf16x2(BEVR_NEG_BIG, BEVR_NEG_BIG);
+    if constexpr (is16(PREC))
+      *reinterpret_cast<unsigned*>(win + (CAP * WIN_PITCH + tid) * ENT) = Half<PREC>::pack2(Half<PREC>::NEG_BIG, Half<PREC>::NEG_BIG);
     else
       *reinterpret_cast<f32x2*>(win + (CAP * WIN_PITCH + tid) * ENT) = f32x2{BEVR_NEG_BIG, BEVR_NEG_BIG};
   }
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
             for (int k = 0; k < PER_WAVE; ++k) {
               const int c = wave + k * NWAVE;
               if (c < CAP) {
-                if constexpr (PREC == BEVR_PREC_BF16)
-                  *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(fv[k][0], fv[k][1]);
+                if constexpr (is16(PREC))
+                  *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = Half<PREC>::pack2(fv[k][0], fv[k][1]);
                 else
                   *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = fv[k];
               }
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
         {
           // launder the row constants: otherwise the splatted 16-register accumulator seeds are hoisted out of the
           // step loop and live in scratch (reloaded every step, a full-latency miss each time)
-          float nl = -lse, nd = -dlt;
+          float nl = kp16 - lse, nd = -dlt;
           asm volatile("" : "+v"(nl), "+v"(nd));
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
         {
           Frag<PREC> vkf;
           vkf.load(base + L::R_BYTES + (kh * 32 + lq) * L::R_STRIDE, hi);
-          if constexpr (PREC == BEVR_PREC_BF16) {
+          if constexpr (is16(PREC)) {
             const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 2 * 64 + lane;
             Frag<PREC> dos;
             dos.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
           // The LDS atomics are ordered memory operations for the compiler: it moves no load across them.  So
           // the loop is software-pipelined by hand -- the taps of key r + 1 and the constants of key r + 2 are
           // requested before the atomics of key r are issued, and their latency hides behind key r's arithmetic.
-          typedef typename std::conditional<PREC == BEVR_PREC_BF16, unsigned, f32x2>::type tap_t;
+          typedef typename std::conditional<is16(PREC), unsigned, f32x2>::type tap_t;
           auto read_tap = [&](int cell, tap_t& a, tap_t& b) {
             const char* p = win + (cell + lq) * ENT;
             a = *reinterpret_cast<const tap_t*>(p);
@@ -486,15 +492,14 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
             if (r + 1 < 16) read_tap(e1.cell, na, nb);
             if (r + 2 < 16) e2 = pk[crow(r + 2, hi)];
             float sv;
-            if constexpr (PREC == BEVR_PREC_BF16) {
-              sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ta), __builtin_bit_cast(bf16x2, e0.wA), s[r],
-                                                   false);
-              sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, tb), __builtin_bit_cast(bf16x2, e0.wB), sv,
-                                                   false);
+            if constexpr (is16(PREC)) {
+              sv = Half<PREC>::dot2(ta, e0.wA, s[r]);
+              sv = Half<PREC>::dot2(tb, e0.wB, sv);
             } else {
               sv = fmaf(tb[1], e0.w11(), fmaf(tb[0], e0.w10(), fmaf(ta[1], e0.w01(), fmaf(ta[0], e0.w00(), s[r]))));
             }
-            const float ds = fast_exp2(sv) * dp[r];   // masked keys: -1e30 from the kill column => 0
+            float ds = fast_exp2(sv) * dp[r];   // masked keys: a huge negative tap from the kill column => 0
+            if constexpr (PREC == BEVR_PREC_F16) ds *= c2_16;   // P' (dP - delta) c2: inside fp16's normal range
             s[r] = ds;
             // table gradient.  Table row (A + l) of column X receives  w00 dS[query l] + w01 dS[query l - 1]  (the
             // upper tap of query l and the lower tap of the query above it); lane l adds exactly that, lane 31 the
@@ -518,6 +523,22 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
                   "v_cvt_rpi_i32_f32 %1, %1"
                   : "=&v"(iA), "=&v"(iB)
                   : "v"(pr), "v"(e0.wA), "v"(e0.wB));
+              atomicAdd(gp, Acc::from_int(iA));
+              atomicAdd(gp + WIN_PITCH, Acc::from_int(iB));
+            } else if constexpr (PREC == BEVR_PREC_F16) {
+              // the same with fp16 operands; the dot products come out in dS16 units and are brought to cell units
+              // (x cfix = 2^16) in f32 before the round-to-integer
+              const unsigned pr = Half<PREC>::pack2(g, gb_);
+              int iA, iB;
+              asm("v_dot2_f32_f16 %0, %2, %3, 0\n\t"
+                  "v_dot2_f32_f16 %1, %2, %4, 0\n\t"
+                  "s_nop 2\n\t"
+                  "v_mul_f32 %0, %0, %5\n\t"
+                  "v_mul_f32 %1, %1, %5\n\t"
+                  "v_cvt_rpi_i32_f32 %0, %0\n\t"
+                  "v_cvt_rpi_i32_f32 %1, %1"
+                  : "=&v"(iA), "=&v"(iB)
+                  : "v"(pr), "v"(e0.wA), "v"(e0.wB), "v"(cfix));
               atomicAdd(gp, Acc::from_int(iA));
               atomicAdd(gp + WIN_PITCH, Acc::from_int(iB));
             } else {
@@ -549,12 +570,12 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
         load_perm(ktf, base + 2 * L::R_BYTES + lq * L::T_STRIDE + kh * 32 * EB, hi);
         f32x16 s, dp;
         {
-          float nl = -lse, nd = -dlt;
+          float nl = kp16 - lse, nd = -dlt;
           asm volatile("" : "+v"(nl), "+v"(nd));
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[r] = nl; dp[r] = nd; }
         }
-        if constexpr (PREC == BEVR_PREC_BF16) {
+        if constexpr (is16(PREC)) {
           const u32x4* qd = reinterpret_cast<const u32x4*>(qdo) + col * 2 * 64 + lane;
           Frag<PREC> dos;
           dos.v[0] = __builtin_bit_cast(bf16x8, qd[0]);
@@ -581,12 +602,13 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
           float sv = s[r] + u0 + fx * (u1 - u0);
           if (last && step * KT + kh * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
           float ds = fast_exp2(sv) * dp[r];
+          if constexpr (PREC == BEVR_PREC_F16) ds *= c2_16;
           s[r] = ds;
           if (ds != 0.f) {
             // plain transposed table, row pitch Hp + 1
             int yi = (c.aoff >> 3) - xoffHp + ilane;
             float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
-            float w0 = ginv * ds * (1.0f - fx), w1 = ginv * ds * fx;   // ginv = ln2 2^-e
+            float w0 = dq_scale * ds * (1.0f - fx), w1 = dq_scale * ds * fx;   // ln2 / (the scale ds carries)
             atomicAdd(g0, w0 * wy0);
             atomicAdd(g0 + 1, w0 * c.fy);
             atomicAdd(g0 + Hq, w1 * wy0);
@@ -617,7 +639,7 @@ __global__ __launch_bounds__(TQ, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_bwd_q
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 v;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = ginv * dq[4 * g4 + k];
+      for (int k = 0; k < 4; ++k) v[k] = dq_scale * dq[4 * g4 + k];
       *reinterpret_cast<f32x4*>(row + 8 * g4 + 4 * hi) = v;
     }
   }
@@ -654,5 +676,7 @@ extern "C" int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const voi
   if (d->precision == BEVR_PREC_BF16)
     return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable,
                                   st);
+  if (d->precision == BEVR_PREC_F16)
+    return launch<BEVR_PREC_F16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
   return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
 }

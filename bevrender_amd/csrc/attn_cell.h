@@ -37,12 +37,12 @@ constexpr int CELL_R = 4;   // table rows per chunk
 // as A (lane = key, forward orientation S^T[key][query]) or as B (key-side backward, S[query][key]).
 //   bf16: element e of lane half h  <->  cell k' = 8 h + e      = (column 2 h + (e >> 2), row e & 3)
 //   f32 : step t    of lane half h  <->  cell k' = 2 t + h      = (column t >> 1,         row 2 (t & 1) + h)
-template <int PREC> struct CellFrag;
-template <> struct CellFrag<BEVR_PREC_BF16> { bf16x8 v; };
+template <int PREC> struct CellFrag { bf16x8 v; };                 // the 16-bit operand modes (raw bits)
 template <> struct CellFrag<BEVR_PREC_F32> { float v[8]; };
 
-__device__ __forceinline__ f32x16 mma_cell(const CellFrag<BEVR_PREC_BF16>& a, const CellFrag<BEVR_PREC_BF16>& b, f32x16 acc) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+template <int PREC>
+__device__ __forceinline__ f32x16 mma_cell(const CellFrag<PREC>& a, const CellFrag<PREC>& b, f32x16 acc) {
+  return Half<PREC>::mfma(a.v, b.v, acc);
 }
 __device__ __forceinline__ f32x16 mma_cell(const CellFrag<BEVR_PREC_F32>& a, const CellFrag<BEVR_PREC_F32>& b, f32x16 acc) {
 #pragma unroll
@@ -54,18 +54,17 @@ __device__ __forceinline__ float hat(float u) { return fmaxf(1.0f - fabsf(u), 0.
 
 // Bilinear weights of this lane's key over the chunk's cells.  tcol = tx - x0 (column coordinate relative to chunk
 // column 0: integer part = first tap column, fraction = fx), trow = a - A0 likewise.  A masked key passes tcol = -8.
-template <int PREC> __device__ __forceinline__ CellFrag<PREC> cell_weights(float tcol, float trow, int h);
-template <> __device__ __forceinline__ CellFrag<BEVR_PREC_BF16> cell_weights<BEVR_PREC_BF16>(float tcol, float trow, int h) {
+template <int PREC> __device__ __forceinline__ CellFrag<PREC> cell_weights(float tcol, float trow, int h) {
   const float wx0 = hat((float)(2 * h) - tcol), wx1 = hat((float)(2 * h + 1) - tcol);
   float wy[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) wy[r] = hat((float)r - trow);
   u32x4 w;
-  w[0] = pack_bf16x2(wx0 * wy[0], wx0 * wy[1]);
-  w[1] = pack_bf16x2(wx0 * wy[2], wx0 * wy[3]);
-  w[2] = pack_bf16x2(wx1 * wy[0], wx1 * wy[1]);
-  w[3] = pack_bf16x2(wx1 * wy[2], wx1 * wy[3]);
-  CellFrag<BEVR_PREC_BF16> f;
+  w[0] = Half<PREC>::pack2(wx0 * wy[0], wx0 * wy[1]);
+  w[1] = Half<PREC>::pack2(wx0 * wy[2], wx0 * wy[3]);
+  w[2] = Half<PREC>::pack2(wx1 * wy[0], wx1 * wy[1]);
+  w[3] = Half<PREC>::pack2(wx1 * wy[2], wx1 * wy[3]);
+  CellFrag<PREC> f;
   f.v = __builtin_bit_cast(bf16x8, w);
   return f;
 }
@@ -86,10 +85,7 @@ template <> __device__ __forceinline__ CellFrag<BEVR_PREC_F32> cell_weights<BEVR
 // padded table: a cell outside it is never given a non-zero weight (the keys' coordinates are clamped so that their
 // taps stay inside, attn_keyprep.hip), so what a clamped read returns is irrelevant as long as it is finite.
 template <int PREC>
-__device__ __forceinline__ CellFrag<PREC> cell_table(const char* tbl, const bevr_attn_desc& d, int xc0, int yr0, int h);
-template <>
-__device__ __forceinline__ CellFrag<BEVR_PREC_BF16> cell_table<BEVR_PREC_BF16>(const char* tbl, const bevr_attn_desc& d,
-                                                                               int xc0, int yr0, int h) {
+__device__ __forceinline__ CellFrag<PREC> cell_table(const char* tbl, const bevr_attn_desc& d, int xc0, int yr0, int h) {
   const int e0 = max(0, min(yr0 + d.y_off, d.Hp - 1)), e2 = max(0, min(yr0 + d.y_off + 2, d.Hp - 1));
   u32x4 w;
 #pragma unroll
@@ -98,10 +94,10 @@ __device__ __forceinline__ CellFrag<BEVR_PREC_BF16> cell_table<BEVR_PREC_BF16>(c
     const char* col = tbl + (size_t)xc * d.Hp * 8;
     const f32x2 p0 = *reinterpret_cast<const f32x2*>(col + (size_t)e0 * 8);   // (T[y], T[y + 1])
     const f32x2 p2 = *reinterpret_cast<const f32x2*>(col + (size_t)e2 * 8);   // (T[y + 2], T[y + 3])
-    w[2 * cc] = pack_bf16x2(p0[0], p0[1]);
-    w[2 * cc + 1] = pack_bf16x2(p2[0], p2[1]);
+    w[2 * cc] = Half<PREC>::pack2(p0[0], p0[1]);
+    w[2 * cc + 1] = Half<PREC>::pack2(p2[0], p2[1]);
   }
-  CellFrag<BEVR_PREC_BF16> f;
+  CellFrag<PREC> f;
   f.v = __builtin_bit_cast(bf16x8, w);
   return f;
 }

@@ -27,10 +27,7 @@ constexpr int KEYS_WGC = TWC / 2;    // 384 keys per workgroup
 // derivative weights of this lane's key over the chunk (see the header): cn / rn = first tap column / row relative to the
 // chunk origin (integers), wx / wy as cell_weights
 template <int PREC>
-__device__ __forceinline__ void cell_dweights(float tcol, float trow, int h, CellFrag<PREC>& wyf, CellFrag<PREC>& wxf);
-template <>
-__device__ __forceinline__ void cell_dweights<BEVR_PREC_BF16>(float tcol, float trow, int h, CellFrag<BEVR_PREC_BF16>& wyf,
-                                                              CellFrag<BEVR_PREC_BF16>& wxf) {
+__device__ __forceinline__ void cell_dweights(float tcol, float trow, int h, CellFrag<PREC>& wyf, CellFrag<PREC>& wxf) {
   const float cn = floorf(tcol), rn = floorf(trow);
   float wx[2], dx[2], wy[4], dy[4];
 #pragma unroll
@@ -47,17 +44,16 @@ __device__ __forceinline__ void cell_dweights<BEVR_PREC_BF16>(float tcol, float 
   u32x4 a, b;
 #pragma unroll
   for (int cc = 0; cc < 2; ++cc) {
-    a[2 * cc] = pack_bf16x2(wx[cc] * dy[0], wx[cc] * dy[1]);
-    a[2 * cc + 1] = pack_bf16x2(wx[cc] * dy[2], wx[cc] * dy[3]);
-    b[2 * cc] = pack_bf16x2(dx[cc] * wy[0], dx[cc] * wy[1]);
-    b[2 * cc + 1] = pack_bf16x2(dx[cc] * wy[2], dx[cc] * wy[3]);
+    a[2 * cc] = Half<PREC>::pack2(wx[cc] * dy[0], wx[cc] * dy[1]);
+    a[2 * cc + 1] = Half<PREC>::pack2(wx[cc] * dy[2], wx[cc] * dy[3]);
+    b[2 * cc] = Half<PREC>::pack2(dx[cc] * wy[0], dx[cc] * wy[1]);
+    b[2 * cc + 1] = Half<PREC>::pack2(dx[cc] * wy[2], dx[cc] * wy[3]);
   }
   wyf.v = __builtin_bit_cast(bf16x8, a);
   wxf.v = __builtin_bit_cast(bf16x8, b);
 }
-template <>
-__device__ __forceinline__ void cell_dweights<BEVR_PREC_F32>(float tcol, float trow, int h, CellFrag<BEVR_PREC_F32>& wyf,
-                                                             CellFrag<BEVR_PREC_F32>& wxf) {
+__device__ __forceinline__ void cell_dweights(float tcol, float trow, int h, CellFrag<BEVR_PREC_F32>& wyf,
+                                              CellFrag<BEVR_PREC_F32>& wxf) {
   const float cn = floorf(tcol), rn = floorf(trow);
   float wy[2], dy[2];
 #pragma unroll
@@ -82,9 +78,12 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ Qt, const char* __restrict__ K,
     const char* __restrict__ V, const char* __restrict__ key_ws, const char* __restrict__ table_pair,
     const char* __restrict__ dO, const char* __restrict__ dOt, const float* __restrict__ LSE,
-    const float* __restrict__ delta, float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dkey_a,
-    float* __restrict__ dkey_b) {
+    const float* __restrict__ delta, const float* __restrict__ grad_scale, float* __restrict__ dK,
+    float* __restrict__ dV, float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
   typedef LdsK<PREC, 1> L;
+  // fp16 mode (include/bevrender_hip.h, grad_scale[2..5]): P' = P 2^kp, dS16 = P' (dP - delta) c2
+  const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
+  const float ds_inv = PREC == BEVR_PREC_F16 ? grad_scale[4] : 1.f, p_inv = PREC == BEVR_PREC_F16 ? grad_scale[5] : 1.f;
   constexpr int EB = L::EB;
   __shared__ __attribute__((aligned(16))) char smem[2 * L::BUF];
 
@@ -140,21 +139,21 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
   CellTile ct = make_celltile(sb, 0.f);
   CellFrag<PREC> wf, wyf, wxf;
   float jr = 0.f;
-  constexpr int NCOLP = PREC == BEVR_PREC_BF16 ? 2 : 4;   // table columns this lane half reads (attn_cell.h lane maps)
+  constexpr int NCOLP = is16(PREC) ? 2 : 4;   // table columns this lane half reads (attn_cell.h lane maps)
   const char* colp[NCOLP];
 #pragma unroll
   for (int c = 0; c < NCOLP; ++c) colp[c] = tbl;
   // raw table entries of a tile's chunk for this lane: bf16 mode 2 columns x (T[y..y+1], T[y+2..y+3]); f32 mode 4 columns x
   // (T[y + hi], T[y + hi + 2])
-  constexpr int NRAW = PREC == BEVR_PREC_BF16 ? 4 : 8;
-  typedef typename std::conditional<PREC == BEVR_PREC_BF16, f32x2, float>::type raw_t;
+  constexpr int NRAW = is16(PREC) ? 4 : 8;
+  typedef typename std::conditional<is16(PREC), f32x2, float>::type raw_t;
   raw_t traw[NRAW];
 #pragma unroll
   for (int k = 0; k < NRAW; ++k) traw[k] = raw_t{};
   auto load_raw = [&](raw_t* dst, int rb_) {
     // rows ct.a0 + rb * 32 + lq (+ 0..3): never below the padded table's first row (a0 >= -(Sp + 1), y_off = Sp + 2)
     const int yr = ct.a0 + rb_ * 32 + lq + d.y_off;
-    if constexpr (PREC == BEVR_PREC_BF16) {
+    if constexpr (is16(PREC)) {
       const int e0 = min(yr, d.Hp - 1) * 8, e2 = min(yr + 2, d.Hp - 1) * 8;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
   QStage<PREC, TWC, 1> qs;
   qs.init(tid, Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB, dO + ((size_t)ph * Mp) * 32 * EB,
           Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB, dOt + ((size_t)ph * 32) * Mp * EB,
-          LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp);
+          LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp, kp16);
   // tile it = (BEV column j = it / n_rb, row block rb = it % n_rb) is the 32 packed queries [32 it, 32 it + 32)
   const int n_it = d.S * n_rb;
   qs.load(tid, 0);
@@ -197,10 +196,10 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
           float tcol, trow;
           cell_coords(kw, jr, ct.x0, dead, tcol, trow);
           wf = cell_weights<PREC>(tcol, trow, hi);
-          cell_dweights<PREC>(tcol, trow, hi, wyf, wxf);
+          cell_dweights(tcol, trow, hi, wyf, wxf);
 #pragma unroll
           for (int c = 0; c < NCOLP; ++c) {
-            const int xc = ct.x0 + (PREC == BEVR_PREC_BF16 ? 2 * hi + c : c) + d.x_off;
+            const int xc = ct.x0 + (is16(PREC) ? 2 * hi + c : c) + d.x_off;
             colp[c] = tbl + (size_t)max(0, min(xc, d.Wp - 1)) * Hp8;
           }
         }
@@ -238,10 +237,10 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
       float sa = 0.f, sbb = 0.f;
       if constexpr (!SLOW) {
         CellFrag<PREC> tf;
-        if constexpr (PREC == BEVR_PREC_BF16) {
+        if constexpr (is16(PREC)) {
           u32x4 w;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(traw[k][0], traw[k][1]);
+          for (int k = 0; k < 4; ++k) w[k] = Half<PREC>::pack2(traw[k][0], traw[k][1]);
           tf.v = __builtin_bit_cast(bf16x8, w);
         } else {
 #pragma unroll
@@ -252,7 +251,8 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
         for (int r = 0; r < 16; r += 2) {
           f32x2 pp = {fast_exp2(s[r]), fast_exp2(s[r + 1])};
           if (any_dead) pp = dead ? f32x2{0.f, 0.f} : pp;
-          const f32x2 ds = pp * f32x2{dp[r], dp[r + 1]};   // dS = P (dP - delta); ln2 folded into the epilogue
+          f32x2 ds = pp * f32x2{dp[r], dp[r + 1]};   // dS = P (dP - delta); ln2 folded into the epilogue
+          if constexpr (PREC == BEVR_PREC_F16) ds *= f32x2{c2_16, c2_16};
           s[r] = pp[0]; s[r + 1] = pp[1];
           dp[r] = ds[0]; dp[r + 1] = ds[1];
         }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
           const float u1 = t1[0] * wy0 + t1[1] * kw.fy;
           const float sv = s[r] + u0 + fx * (u1 - u0);
           const float p = dead ? 0.f : fast_exp2(sv);
-          const float ds = p * dp[r];
+          const float ds = p * dp[r] * c2_16;
           s[r] = p;
           dp[r] = ds;
           const float ga = (t0[1] - t0[0]) + fx * ((t1[1] - t1[0]) - (t0[1] - t0[0]));
@@ -327,12 +327,12 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
         b = *reinterpret_cast<const f32x4*>(vr + 8 * g4 + 4 * hi);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { a[k] += BEVR_LN2 * dk[4 * g4 + k]; b[k] += dv[4 * g4 + k]; }
+      for (int k = 0; k < 4; ++k) { a[k] += BEVR_LN2 * ds_inv * dk[4 * g4 + k]; b[k] += p_inv * dv[4 * g4 + k]; }
       *reinterpret_cast<f32x4*>(kr + 8 * g4 + 4 * hi) = a;
       *reinterpret_cast<f32x4*>(vr + 8 * g4 + 4 * hi) = b;
     }
-    const float sa = BEVR_LN2 * (da + __shfl_xor(da, 32));
-    const float sb2 = BEVR_LN2 * (db + __shfl_xor(db, 32));
+    const float sa = BEVR_LN2 * ds_inv * (da + __shfl_xor(da, 32));
+    const float sb2 = BEVR_LN2 * ds_inv * (db + __shfl_xor(db, 32));
     if (hi == 0) {
       atomicAdd(dkey_a + (size_t)pg * d.Np + key, sa);
       atomicAdd(dkey_b + (size_t)pg * d.Np + key, sb2);
@@ -342,19 +342,19 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
 
 template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K, const void* V, const void* key_ws,
-           const float* table_pair, const void* dO, const void* dOt, const float* LSE, const float* delta, float* dK,
-           float* dV, float* dka, float* dkb, hipStream_t st) {
+           const float* table_pair, const void* dO, const void* dOt, const float* LSE, const float* delta,
+           const float* gs, float* dK, float* dV, float* dka, float* dkb, hipStream_t st) {
   const int n_kb = (d.Np + KEYS_WGC - 1) / KEYS_WGC;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_kb;
   hipLaunchKernelGGL((attn_cell_bwd_k_kernel<PREC, false>), dim3(grid), dim3(TWC), 0, st, d, (const char*)Q,
                      (const char*)Qt, (const char*)K, (const char*)V, (const char*)key_ws, (const char*)table_pair,
-                     (const char*)dO, (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
+                     (const char*)dO, (const char*)dOt, LSE, delta, gs, dK, dV, dka, dkb);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL((attn_cell_bwd_k_kernel<PREC, true>), dim3(grid), dim3(TWC), 0, st, d, (const char*)Q,
                      (const char*)Qt, (const char*)K, (const char*)V, (const char*)key_ws, (const char*)table_pair,
-                     (const char*)dO, (const char*)dOt, LSE, delta, dK, dV, dka, dkb);
+                     (const char*)dO, (const char*)dOt, LSE, delta, gs, dK, dV, dka, dkb);
   return (int)hipGetLastError();
 }
 
@@ -362,12 +362,12 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K
 
 extern "C" int bevr_attn_cell_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
                                     const void* key_ws, const float* table_pair, const void* dO, const void* dOt,
-                                    const float* LSE, const float* delta, float* dK, float* dV, float* dkey_a,
-                                    float* dkey_b, void* stream) {
+                                    const float* LSE, const float* delta, const float* grad_scale, float* dK,
+                                    float* dV, float* dkey_a, float* dkey_b, void* stream) {
   int rc = bevr_check_desc(d);
   if (rc) return rc;
   if (!Q || !Qt || !K || !V || !key_ws || !table_pair || !dO || !dOt || !LSE || !delta || !dK || !dV || !dkey_a ||
-      !dkey_b)
+      !dkey_b || (d->precision == BEVR_PREC_F16 && !grad_scale))
     return BEVR_E_NULL;
   if (!bevr_aligned16(Q) || !bevr_aligned16(Qt) || !bevr_aligned16(K) || !bevr_aligned16(V) || !bevr_aligned16(dO) ||
       !bevr_aligned16(dOt) || !bevr_aligned16(dK) || !bevr_aligned16(dV) || !bevr_aligned16(table_pair) ||
@@ -375,6 +375,11 @@ extern "C" int bevr_attn_cell_bwd_k(const bevr_attn_desc* d, const void* Q, cons
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
-    return launch<BEVR_PREC_BF16>(*d, Q, Qt, K, V, key_ws, table_pair, dO, dOt, LSE, delta, dK, dV, dkey_a, dkey_b, st);
-  return launch<BEVR_PREC_F32>(*d, Q, Qt, K, V, key_ws, table_pair, dO, dOt, LSE, delta, dK, dV, dkey_a, dkey_b, st);
+    return launch<BEVR_PREC_BF16>(*d, Q, Qt, K, V, key_ws, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV, dkey_a,
+                                  dkey_b, st);
+  if (d->precision == BEVR_PREC_F16)
+    return launch<BEVR_PREC_F16>(*d, Q, Qt, K, V, key_ws, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV, dkey_a,
+                                 dkey_b, st);
+  return launch<BEVR_PREC_F32>(*d, Q, Qt, K, V, key_ws, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV, dkey_a,
+                               dkey_b, st);
 }

@@ -41,7 +41,7 @@ template <int PREC> struct LdsCQ {
   static constexpr int TCH_ROW = KT * EB / 16;
   static constexpr int CH = KT * RCH_ROW;
   static constexpr int NCH = 3 * CH + KT;
-  static constexpr int NST = PREC == BEVR_PREC_BF16 ? 2 : 4;
+  static constexpr int NST = is16(PREC) ? 2 : 4;
   static constexpr int QCH = 32 * EB / 16 / 2;      // 16-B chunks of one lane's fragment: 2 (bf16) / 4 (f32)
   static constexpr int QSLOT = 2 * QCH * 1024;      // per wave: Q then dO, each [chunk][lane]
 };
@@ -71,16 +71,17 @@ __device__ __forceinline__ void chunk_map_q(int g, const char* Kh, const char* V
 
 // acc1 += A1 * X, acc2 += A2 * X with X an accumulator-layout tile used as the B operand of both (bevr_common.h:
 // mma_acc_b), converted to bf16 once.
-__device__ __forceinline__ void mma_acc_b2(const Frag<BEVR_PREC_BF16>& a1, const Frag<BEVR_PREC_BF16>& a2, const f32x16& x,
-                                           f32x16& acc1, f32x16& acc2) {
+template <int PREC>
+__device__ __forceinline__ void mma_acc_b2(const Frag<PREC>& a1, const Frag<PREC>& a2, const f32x16& x, f32x16& acc1,
+                                           f32x16& acc2) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     u32x4 w;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = pack_bf16x2(x[8 * s + 2 * k], x[8 * s + 2 * k + 1]);
+    for (int k = 0; k < 4; ++k) w[k] = Half<PREC>::pack2(x[8 * s + 2 * k], x[8 * s + 2 * k + 1]);
     const bf16x8 b = __builtin_bit_cast(bf16x8, w);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.v[s], b, acc1, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.v[s], b, acc2, 0, 0, 0);
+    acc1 = Half<PREC>::mfma(a1.v[s], b, acc1);
+    acc2 = Half<PREC>::mfma(a2.v[s], b, acc2);
   }
 }
 __device__ __forceinline__ void mma_acc_b2(const Frag<BEVR_PREC_F32>& a1, const Frag<BEVR_PREC_F32>& a2, const f32x16& x,
@@ -94,8 +95,12 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Kt,
     const char* __restrict__ V, const char* __restrict__ key_ws, const char* __restrict__ table_pair,
     const char* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
-    float* __restrict__ dQ, float* __restrict__ dtable) {
+    const float* __restrict__ grad_scale, float* __restrict__ dQ, float* __restrict__ dtable) {
   typedef LdsCQ<PREC> L;
+  // fp16 mode (include/bevrender_hip.h, grad_scale[2..5]): P' = P 2^kp, dS16 = P' (dP - delta) c2 -- both inside fp16's
+  // normal range; dQ and the table gradient are accumulated in dS16 units and unscaled on the way out
+  const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
+  const float out_scale = BEVR_LN2 * (PREC == BEVR_PREC_F16 ? grad_scale[4] : 1.f);
   constexpr int EB = L::EB;
   // 2 staging buffers | a (Q, dO) fragment slot per wave | (slow pass) the list of this column's slow tiles
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
   // tile; slot layout [chunk][lane]: consecutive lanes read consecutive 16 B (a per-lane slot of 64 / 128 B put 4 / 8
   // lanes of a ds_read_b128 group on the same banks: measured 65 % of this kernel's LDS cycles)
   auto put_frag = [&](char* dst, const Frag<PREC>& f, bool zero) {
-    if constexpr (PREC == BEVR_PREC_BF16) {
+    if constexpr (is16(PREC)) {
       const u32x4 z = {0, 0, 0, 0};
       *reinterpret_cast<u32x4*>(dst) = zero ? z : __builtin_bit_cast(u32x4, f.v[0]);
       *reinterpret_cast<u32x4*>(dst + 1024) = zero ? z : __builtin_bit_cast(u32x4, f.v[1]);
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
     }
   };
   auto get_frag = [&](const char* src, Frag<PREC>& f) {
-    if constexpr (PREC == BEVR_PREC_BF16) {
+    if constexpr (is16(PREC)) {
       f.v[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src));
       f.v[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(src + 1024));
     } else {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
 
   CellFrag<PREC> tf;
   int tag_x = 1 << 30, tag_a = 1 << 30;
-  if constexpr (PREC == BEVR_PREC_BF16) tf.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (is16(PREC)) tf.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) tf.v[k] = 0.f;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
       for (int r = 0; r < 8; ++r) {
         const int c = 2 * (r >> 2) + hi, row = r & 3;
         const int xc = tag_x + c + d.x_off, yr = tag_a + row + i0 + lq + d.y_off;
-        const float v = y[r] * BEVR_LN2;
+        const float v = y[r] * out_scale;
         if (v != 0.f && xc >= 0 && xc < d.Wp && yr >= 0 && yr < Hq) atomicAdd(dtb + (size_t)xc * Hq + yr, v);
       }
     }
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
       }
       CellFrag<PREC> wf;
       const char* wsrc = base + L::OFF_W + (t * 64 + lane) * L::WL;
-      if constexpr (PREC == BEVR_PREC_BF16) {
+      if constexpr (is16(PREC)) {
         wf.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc));
       } else {
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc), w1 = *reinterpret_cast<const f32x4*>(wsrc + 16);
@@ -265,12 +270,13 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
         for (int r = 0; r < 16; ++r) s[r] = (step * KT + t * 32 + crow(r, hi) >= d.N) ? BEVR_NEG_BIG : s[r];
       }
       // P = exp2(S - LSE), dS = P (dP - delta), two rows per instruction; ln2 applied on the way out
-      const f32x2 nl = {-lse, -lse}, nd = {-dlt, -dlt};
+      const f32x2 nl = {kp16 - lse, kp16 - lse}, nd = {-dlt, -dlt};
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 sh = f32x2{s[r], s[r + 1]} + nl;
         const f32x2 pp = {fast_exp2(sh[0]), fast_exp2(sh[1])};
-        const f32x2 ds = pp * (f32x2{dp[r], dp[r + 1]} + nd);
+        f32x2 ds = pp * (f32x2{dp[r], dp[r + 1]} + nd);
+        if constexpr (PREC == BEVR_PREC_F16) ds *= f32x2{c2_16, c2_16};
         s[r] = ds[0];
         s[r + 1] = ds[1];
       }
@@ -296,14 +302,14 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
         const f32x2 t1 = *reinterpret_cast<const f32x2*>(tbl + off + Hp8);
         const float u0 = t0[0] * wy0 + t0[1] * c.fy;
         const float u1 = t1[0] * wy0 + t1[1] * c.fy;
-        float sv = s[r] - lse + u0 + fx * (u1 - u0);
+        float sv = s[r] + (kp16 - lse) + u0 + fx * (u1 - u0);
         if (last && step * KT + t * 32 + crow(r, hi) >= d.N) sv = BEVR_NEG_BIG;
-        const float ds = fast_exp2(sv) * (dp[r] - dlt);
+        const float ds = fast_exp2(sv) * (dp[r] - dlt) * c2_16;
         s[r] = ds;
         if (ds != 0.f) {
           const int yi = (c.aoff >> 3) - xoffHp + i0 + lq;
           float* g0 = dtb + (size_t)(xi + d.x_off) * Hq + yi;
-          const float w0 = BEVR_LN2 * ds * (1.0f - fx), w1 = BEVR_LN2 * ds * fx;
+          const float w0 = out_scale * ds * (1.0f - fx), w1 = out_scale * ds * fx;
           atomicAdd(g0, w0 * wy0);
           atomicAdd(g0 + 1, w0 * c.fy);
           atomicAdd(g0 + Hq, w1 * wy0);
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
       char* bb = smem + buf * L::BUF;
       char* dst = bb + L::OFF_W + (t * 64 + lane) * L::WL;
       char* wt = bb + L::OFF_WT + t * L::WT_TILE + perm32(lq) * EB;
-      if constexpr (PREC == BEVR_PREC_BF16) {
+      if constexpr (is16(PREC)) {
         const u32x4 wv = __builtin_bit_cast(u32x4, w.v);
         *reinterpret_cast<u32x4*>(dst) = wv;
 #pragma unroll
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * g4 + 4 * hi);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] += BEVR_LN2 * dq[4 * g4 + k];
+      for (int k = 0; k < 4; ++k) v[k] += out_scale * dq[4 * g4 + k];
       *reinterpret_cast<f32x4*>(row + 8 * g4 + 4 * hi) = v;
     }
   }
@@ -471,8 +477,8 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
 
 template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt, const void* V, const void* key_ws,
-           const float* table_pair, const void* dO, const float* LSE, const float* delta, float* dQ, float* dtable,
-           hipStream_t st) {
+           const float* table_pair, const void* dO, const float* LSE, const float* delta, const float* gs, float* dQ,
+           float* dtable, hipStream_t st) {
   typedef LdsCQ<PREC> L;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * d.S;
@@ -482,12 +488,12 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt
   if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
   hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
                      (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
-                     (const char*)dO, LSE, delta, dQ, dtable);
+                     (const char*)dO, LSE, delta, gs, dQ, dtable);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d,
                      (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
-                     (const char*)table_pair, (const char*)dO, LSE, delta, dQ, dtable);
+                     (const char*)table_pair, (const char*)dO, LSE, delta, gs, dQ, dtable);
   return (int)hipGetLastError();
 }
 
@@ -495,16 +501,21 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt
 
 extern "C" int bevr_attn_cell_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
                                     const void* key_ws, const float* table_pair, const void* dO, const float* LSE,
-                                    const float* delta, float* dQ, float* dtable, void* stream) {
+                                    const float* delta, const float* grad_scale, float* dQ, float* dtable,
+                                    void* stream) {
   int rc = bevr_check_desc(d);
   if (rc) return rc;
-  if (!Q || !K || !Kt || !V || !key_ws || !table_pair || !dO || !LSE || !delta || !dQ || !dtable) return BEVR_E_NULL;
+  if (!Q || !K || !Kt || !V || !key_ws || !table_pair || !dO || !LSE || !delta || !dQ || !dtable ||
+      (d->precision == BEVR_PREC_F16 && !grad_scale))
+    return BEVR_E_NULL;
   if (d->Sp > 512) return BEVR_E_SHAPE;
   if (!bevr_aligned16(Q) || !bevr_aligned16(K) || !bevr_aligned16(Kt) || !bevr_aligned16(V) || !bevr_aligned16(dO) ||
       !bevr_aligned16(dQ) || !bevr_aligned16(table_pair) || !bevr_aligned16(key_ws))
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
-    return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, dQ, dtable, st);
-  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, dQ, dtable, st);
+    return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
+  if (d->precision == BEVR_PREC_F16)
+    return launch<BEVR_PREC_F16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
+  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
 }

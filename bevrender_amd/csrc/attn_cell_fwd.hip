@@ -27,11 +27,21 @@
 #include <type_traits>
 #include "attn_cell.h"
 
+#ifndef BEVR_VARIANT
+#define BEVR_VARIANT 0
+#endif
+
 namespace {
 
 constexpr float MASS_THR = 4.0f;      // move the reference up when a tile's mass exceeds this: every weight <= 4 = 2^2
 constexpr float LOG2_MASS_THR = 2.0f; // ... which is also the slack of LSE plane 1 (as attn_fwd.hip's RESCALE_THR)
 constexpr float MASS_REDO = 1.0e18f;  // a tile this heavy (or inf / NaN) is redone with its exact maximum
+// fp16 operands: the reference sits Half::SHIFT = 10 binades under the maximum (attn_fwd.hip), weights may reach 2^12
+// before the reference moves, and a tile whose mass nears fp16's largest number (65504) is redone exactly
+template <int PREC> constexpr float shift16() { return PREC == BEVR_PREC_F16 ? 10.0f : 0.0f; }
+template <int PREC> constexpr float mass_thr() { return PREC == BEVR_PREC_F16 ? MASS_THR * 1024.0f : MASS_THR; }
+template <int PREC> constexpr float mass_redo() { return PREC == BEVR_PREC_F16 ? 30000.0f : MASS_REDO; }
+constexpr float CHAIN_SHIFT16 = 12.0f;   // fp16: an incoming (O, LSE) state is re-referenced 12 binades down (l = 2^12)
 
 template <int PREC> struct LdsC {
   static constexpr int EB = Elem<PREC>::bytes;
@@ -50,7 +60,7 @@ template <int PREC> struct LdsC {
   static constexpr int VCH_ROW = KT * EB / 16;      // 16-B chunks per V^T row of this step
   static constexpr int CH = KT * KCH_ROW;           // chunks per tile (K rows, V^T rows): 256 / 512
   static constexpr int NCH = 2 * CH + KT;           // + one KeyW record per key
-  static constexpr int NST = PREC == BEVR_PREC_BF16 ? 2 : 3;   // chunks a thread carries in registers across a step
+  static constexpr int NST = is16(PREC) ? 2 : 3;   // chunks a thread carries in registers across a step
   static constexpr int QCH = 32 * EB / 16 / 2;      // 16-B chunks of one lane's Q fragment: 2 (bf16) / 4 (f32)
   static constexpr int QSLOT = QCH * 1024;          // per wave: [chunk][lane] -- consecutive lanes, consecutive 16 B
 };
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
   {
     Frag<PREC> qf;
     qf.load(Qh + mq * 32 * EB, hi);
-    if constexpr (PREC == BEVR_PREC_BF16) {
+    if constexpr (is16(PREC)) {
       *reinterpret_cast<u32x4*>(qslot) = __builtin_bit_cast(u32x4, qf.v[0]);
       *reinterpret_cast<u32x4*>(qslot + 1024) = __builtin_bit_cast(u32x4, qf.v[1]);
     } else {
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     }
   }
   auto load_q = [&](Frag<PREC>& f) {
-    if constexpr (PREC == BEVR_PREC_BF16) {
+    if constexpr (is16(PREC)) {
       f.v[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qslot));
       f.v[1] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qslot + 1024));
     } else {
@@ -168,6 +178,10 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     }
   };
 
+#if BEVR_VARIANT & 1
+  Frag<PREC> qreg;
+  load_q(qreg);
+#endif
   // ---- online-softmax state --------------------------------------------------------------------------
   f32x16 o;
   float m = 0.f, l = 0.f;
@@ -177,14 +191,17 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     // rows never written hold -inf in the incoming plane: start them from 0 (their results are never read)
     if (__any(lse_in > -3.0e38f)) {
       first = false;
-      m = lse_in > -3.0e38f ? lse_in : 0.f;
-      l = hi == 0 ? 1.f : 0.f;       // the halves' denominators are added in the epilogue
+      // fp16: weights relative to the incoming LSE would sit far below fp16's normal range; the same state re-referenced
+      // CHAIN_SHIFT16 binades down (m - 12, l = 2^12, o = 2^12 O_in) is exact in f32 and keeps them representable
+      constexpr float CS = PREC == BEVR_PREC_F16 ? CHAIN_SHIFT16 : 0.f;
+      m = (lse_in > -3.0e38f ? lse_in : 0.f) - CS;
+      l = hi == 0 ? __builtin_amdgcn_exp2f(CS) : 0.f;       // the halves' denominators are added in the epilogue
       const float* orow = O_in + ((size_t)ph * Mp + mq) * 32;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(orow + 8 * g4 + 4 * hi);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[4 * g4 + k] = v[k];
+        for (int k = 0; k < 4; ++k) o[4 * g4 + k] = v[k] * __builtin_amdgcn_exp2f(CS);
       }
     }
   }
@@ -196,7 +213,7 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
   // ---- one tile: S^T = K Q^T (+ bias), P = exp2(S^T - m), l += sum P, o += V^T P^T -----------------------------
   CellFrag<PREC> tf;          // table operand of the chunk this wave holds, and its origin
   int tag_x = 1 << 30, tag_a = 1 << 30;
-  if constexpr (PREC == BEVR_PREC_BF16) tf.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (is16(PREC)) tf.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) tf.v[k] = 0.f;
@@ -218,15 +235,20 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;   // literal-zero accumulator: no register splat
       {
-        Frag<PREC> kf, qf;
+        Frag<PREC> kf;
         kf.load(base + (t * 32 + lq) * L::K_STRIDE, hi);
+#if BEVR_VARIANT & 1
+        s = mma_frag(kf, qreg, s);
+#else
+        Frag<PREC> qf;
         load_q(qf);
         s = mma_frag(kf, qf, s);   // S^T[key][query]
+#endif
       }
       if constexpr (!SLOW) {
         CellFrag<PREC> wf;
         const char* wsrc = base + L::OFF_W + (t * 64 + lane) * L::WL;
-        if constexpr (PREC == BEVR_PREC_BF16) {
+        if constexpr (is16(PREC)) {
           wf.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc));
         } else {
           const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc), w1 = *reinterpret_cast<const f32x4*>(wsrc + 16);
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
         float tm = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
-        tm = fmaxf(tm, __shfl_xor(tm, 32));   // the lane halves hold the same queries, different keys
+        tm = fmaxf(tm, __shfl_xor(tm, 32)) - shift16<PREC>();   // the lane halves hold the same queries, different keys
         const float mn = first ? tm : fmaxf(m, tm);
         const float al = first ? 0.f : fast_exp2(m - mn);
 #pragma unroll
@@ -276,22 +298,26 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 sh = f32x2{s[r], s[r + 1]} + nm;
+#if BEVR_VARIANT & 16
+        const f32x2 pp = sh * sh;            // timing experiment only: no exp
+#else
         const f32x2 pp = {fast_exp2(sh[0]), fast_exp2(sh[1])};
+#endif
         s[r] = pp[0];
         s[r + 1] = pp[1];
         ls2 += pp;
       }
       const float ts = ls2[0] + ls2[1];
-      if (attempt == 0 && __any(!(ts <= MASS_REDO))) continue;   // overflowed against the old reference: redo exactly
+      if (attempt == 0 && __any(!(ts <= mass_redo<PREC>()))) continue;   // overflowed against the old reference: redo exactly
       l += ts;
       {
         Frag<PREC> vf;
         load_perm(vf, base + L::OFF_V + lq * L::V_STRIDE + t * 32 * EB, hi);
         o = mma_acc_b(vf, s, o);
       }
-      if (__any(ts > MASS_THR)) {   // wave-uniform, rare: keep every committed weight <= MASS_THR of the reference
+      if (__any(ts > mass_thr<PREC>())) {   // wave-uniform, rare: keep every committed weight <= mass_thr of the reference
         const float tb = ts + __shfl_xor(ts, 32);
-        const float up = fmaxf(ceilf(__log2f(tb)), 0.f);
+        const float up = fmaxf(ceilf(__log2f(tb)) - shift16<PREC>(), 0.f);
         const float al = fast_exp2(-up);
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= al;
@@ -346,7 +372,7 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
       const CellFrag<PREC> w = cell_weights<PREC>(tcol, trow, hi);
       char* bb = smem + buf * L::BUF;
       char* dst = bb + L::OFF_W + (t * 64 + lane) * L::WL;
-      if constexpr (PREC == BEVR_PREC_BF16) {
+      if constexpr (is16(PREC)) {
         *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, w.v);
       } else {
         *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
@@ -381,7 +407,11 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
 #pragma unroll
         for (int k = 0; k < L::NST; ++k) {
           st_src[k] += st_inc[k];
+#if BEVR_VARIANT & 64
+          st[k] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};   // timing experiment: no staging loads
+#else
           st[k] = gload16(st_src[k]);
+#endif
         }
       }
       // the next step's key record for the tile this wave builds: loaded unconditionally (a load under a branch is
@@ -391,16 +421,27 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
       const int nstep_c = min(step + 1, n_step - 1);
       const int tb = builder_of(step + 1, 1) == wave ? 1 : 0;
       const bool bld = more && builder_of(step + 1, tb) == wave;
+#if BEVR_VARIANT & 128
+      const KeyW kwn = KeyW{0, 0.3f, 999.2f, 8 * 2};   // timing experiment: no key-record load
+#else
       const KeyW kwn = load_kw(nstep_c, tb);
+#endif
       const StepBox sbb = sb_nxt[tb];
       const StepBox sbo = sb_nxt[1 - tb];
       sb_nxt[0] = kbox[2 * min(step + 2, n_step - 1)];
       sb_nxt[1] = kbox[2 * min(step + 2, n_step - 1) + 1];
 
+#if BEVR_VARIANT & 2
+      const u32x4 cw2[2] = {*reinterpret_cast<const u32x4*>(base + L::OFF_CT), *reinterpret_cast<const u32x4*>(base + L::OFF_CT + 16)};
+#endif
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         // the tile's geometry, computed once by the builder: one broadcast read instead of ~40 instructions per wave
+#if BEVR_VARIANT & 2
+        const u32x4 cw = cw2[t];
+#else
         const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);
+#endif
         const int live = __builtin_amdgcn_readfirstlane((int)cw[0]), fast = __builtin_amdgcn_readfirstlane((int)cw[1]);
         if (!live || !fast) continue;   // nothing to do / the slow pass's tile (uniform)
         tile(std::false_type{}, base, step, t, __builtin_amdgcn_readfirstlane((int)cw[2]),
@@ -416,7 +457,9 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
           *reinterpret_cast<u32x4*>(nb + st_dst[k]) = st[k];
         stage_direct(nb, step + 1, tid + L::NST * nt);
       }
+#if !(BEVR_VARIANT & 32)
       __syncthreads();
+#endif
     }
     if (n_main < n_step) {   // the peeled last step: padded keys masked
       const char* base = smem + (n_main & 1) * L::BUF;
@@ -448,7 +491,7 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     if (hi == 0) {
       Lh[mq] = m + __log2f(lt);
       // plane 1: upper bound of log2 of the row's largest softmax weight (every committed weight <= MASS_THR 2^m)
-      Lh[(size_t)n_ph * Mp + mq] = LOG2_MASS_THR - __log2f(lt);
+      Lh[(size_t)n_ph * Mp + mq] = LOG2_MASS_THR + shift16<PREC>() - __log2f(lt);
     }
   }
 }
@@ -489,5 +532,7 @@ extern "C" int bevr_attn_cell_fwd(const bevr_attn_desc* d, const void* Q, const 
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
     return launch<BEVR_PREC_BF16>(*d, Q, K, Vt, key_ws, table_pair, O_in, LSE_in, O, LSE, st);
+  if (d->precision == BEVR_PREC_F16)
+    return launch<BEVR_PREC_F16>(*d, Q, K, Vt, key_ws, table_pair, O_in, LSE_in, O, LSE, st);
   return launch<BEVR_PREC_F32>(*d, Q, K, Vt, key_ws, table_pair, O_in, LSE_in, O, LSE, st);
 }

@@ -42,6 +42,10 @@ __device__ __forceinline__ unsigned long long prof_now_f(float dep) {
 namespace {
 
 constexpr float RESCALE_THR = 2.0f;  // log2 units: lazy running-max update (P <= 2^2); also the slack of LSE plane 1 in BF16 mode
+// fp16 mode: the reference sits Half::SHIFT = 10 binades under the running maximum (weights up to 2^12, small ones
+// still normal numbers): threshold and plane-1 slack move up by the same amount
+template <int PREC> constexpr float rescale_thr() { return PREC == BEVR_PREC_F16 ? RESCALE_THR + 10.0f : RESCALE_THR; }
+template <int PREC> constexpr float ref_shift() { return PREC == BEVR_PREC_F16 ? 10.0f : 0.0f; }
 constexpr int TF = 512;              // threads per workgroup
 constexpr int NWF = TF / 64;         // waves = query columns per workgroup
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -49,7 +53,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 template <int PREC> struct Lds {
   static constexpr int EB = Elem<PREC>::bytes;
   static constexpr int WIN_COLS = region_cap_fwd(PREC);         // table-region columns
-  static constexpr int ENT = PREC == BEVR_PREC_BF16 ? 4 : 8;    // bytes per window entry: (T[y], T[y+1]) as bf16x2 / f32x2
+  static constexpr int ENT = is16(PREC) ? 4 : 8;    // bytes per window entry: (T[y], T[y+1]) as a 16-bit pair / f32x2
   static constexpr int K_STRIDE = 32 * EB + 16;   // bytes per key row (+16: bank spread)
   static constexpr int V_STRIDE = KT * EB + 16;   // bytes per channel row
   static constexpr int K_BYTES = KT * K_STRIDE;
@@ -57,13 +61,13 @@ template <int PREC> struct Lds {
   static constexpr int C_BYTES = KT * 16 + 32;    // KeyW per key + WinInfo
   static constexpr int BUF = K_BYTES + V_BYTES + C_BYTES;
   static constexpr int WIN = WIN_COLS * WIN_PITCH * ENT;
-  static constexpr int PCK = NWF * KT * (PREC == BEVR_PREC_BF16 ? 16 : 32);   // per-wave (column, key) constants
-  static constexpr int QL = PREC == BEVR_PREC_BF16 ? NWF * 128 * 16 : 16;       // bf16 mode: Q fragments
+  static constexpr int PCK = NWF * KT * (is16(PREC) ? 16 : 32);   // per-wave (column, key) constants
+  static constexpr int QL = is16(PREC) ? NWF * 128 * 16 : 16;       // 16-bit modes: Q fragments
   static constexpr int TOTAL = 2 * BUF + WIN + PCK + QL;
 };
 
 template <int PREC>
-__global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_kernel(
+__global__ __launch_bounds__(TF, is16(PREC) ? 4 : 2) void attn_fwd_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Vt,
     const char* __restrict__ key_ws, const char* __restrict__ table_pair,
     float* __restrict__ O, float* __restrict__ LSE) {
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
   const float jrx = (float)jc * rx;
   Frag<PREC> qf;
   qf.load(Qh + ((size_t)jc * d.Sp + i0 + lq) * 32 * EB, hi);
-  if constexpr (PREC == BEVR_PREC_BF16) {   // bf16 mode: the Q fragment lives in LDS (re-read per tile), not in 8 registers
+  if constexpr (is16(PREC)) {   // 16-bit modes: the Q fragment lives in LDS (re-read per tile), not in 8 registers
     u32x4* ql = reinterpret_cast<u32x4*>(qlds) + wave * 128 + lane;
     ql[0] = __builtin_bit_cast(u32x4, qf.v[0]);
     ql[64] = __builtin_bit_cast(u32x4, qf.v[1]);
@@ -222,8 +226,8 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
 #pragma unroll
       for (int k = 0; k < PER_WAVE; ++k) {
         const int c = wave + k * NWF;
-        if constexpr (PREC == BEVR_PREC_BF16)
-          *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = pack_bf16x2(fv[k][0], fv[k][1]);
+        if constexpr (is16(PREC))
+          *reinterpret_cast<unsigned*>(win + (c * WIN_PITCH + lane) * ENT) = Half<PREC>::pack2(fv[k][0], fv[k][1]);
         else
           *reinterpret_cast<f32x2*>(win + (c * WIN_PITCH + lane) * ENT) = fv[k];
       }
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = -m;
-      if constexpr (PREC == BEVR_PREC_BF16) {   // own lanes' data, written by this wave: no barrier needed
+      if constexpr (is16(PREC)) {   // own lanes' data, written by this wave: no barrier needed
         const u32x4* ql = reinterpret_cast<const u32x4*>(qlds) + wave * 128 + lane;
         Frag<PREC> qs;
         qs.v[0] = __builtin_bit_cast(bf16x8, ql[0]);
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       // relative-position bias: rows of the tile are keys crow(r, hi); lanes are BEV rows i0 + lq.
       if (use_win) {
         const char* wl = win + lqe;
-        if constexpr (PREC == BEVR_PREC_BF16) {
+        if constexpr (is16(PREC)) {
           // hand-pipelined, BIAS_BATCH key rows at a time: all cell reads, then all tap and weight reads, then the dot
           // products -- two LDS latencies per batch instead of two per two or three rows (the compiler's own schedule)
 #ifndef BEVR_BIAS_BATCH
@@ -311,10 +315,8 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < BIAS_BATCH; ++k) {
-              float sv = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, ta[k]),
-                                                         __builtin_bit_cast(bf16x2, wa[k]), s[r0 + k], false);
-              s[r0 + k] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, tb[k]),
-                                                          __builtin_bit_cast(bf16x2, wb[k]), sv, false);
+              const float sv = Half<PREC>::dot2(ta[k], wa[k], s[r0 + k]);
+              s[r0 + k] = Half<PREC>::dot2(tb[k], wb[k], sv);
             }
           }
         } else {
@@ -357,9 +359,9 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
       if constexpr (PREC == BEVR_PREC_F32) smax = fmaxf(smax, tm + m);
       const bool first = (step == 0 && ks == 0);
-      if (first || __any(tm > RESCALE_THR)) {   // wave-uniform: rare after the first tiles
+      if (first || __any(tm > rescale_thr<PREC>())) {   // wave-uniform: rare after the first tiles
         // the two lane halves hold the same queries (different keys): agree on the maximum only when it is needed
-        tm = fmaxf(tm, __shfl_xor(tm, 32));
+        tm = fmaxf(tm, __shfl_xor(tm, 32)) - ref_shift<PREC>();
         const float up = first ? tm : fmaxf(tm, 0.f);   // the max only moves up, except when it is first set
         const float al = fast_exp2(-up);
 #pragma unroll
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(TF, PREC == BEVR_PREC_BF16 ? 4 : 2) void attn_fwd_k
       // BF16 mode: every logit of the row is <= m + RESCALE_THR (a tile above that moves m), so P <= 2^THR / l -- free,
       // where tracking the exact maximum costs a register and 7 % of the kernel at 128 VGPRs.  F32 mode (the parity
       // mode, 212 VGPRs): the exact maximum.
-      Lh[(size_t)n_ph * Mp + mq] = PREC == BEVR_PREC_F32 ? smax_row - lse : RESCALE_THR - __log2f(lt);
+      Lh[(size_t)n_ph * Mp + mq] = PREC == BEVR_PREC_F32 ? smax_row - lse : rescale_thr<PREC>() - __log2f(lt);
     }
   }
 }
@@ -449,5 +451,6 @@ extern "C" int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void*
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16) return launch_fwd<BEVR_PREC_BF16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
+  if (d->precision == BEVR_PREC_F16) return launch_fwd<BEVR_PREC_F16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
   return launch_fwd<BEVR_PREC_F32>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
 }

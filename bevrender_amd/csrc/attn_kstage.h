@@ -14,7 +14,7 @@ template <int PREC, int NT = 1> struct LdsK {
   static constexpr int TILE_T = 32 * TSTRIDE;
   static constexpr int TILE = TILE_Q;                     // NT = 1: all four tiles are 32 rows x 32 elements
   static constexpr int BUF = 2 * TILE_Q + 2 * TILE_T + 2 * QTILE * 4;  // Q, dO, Qt, dOt, lse, delta
-  static constexpr int WCAP = PREC == BEVR_PREC_BF16 ? 30720 : 26624;   // ring capacity, f32 entries (one workgroup per CU)
+  static constexpr int WCAP = is16(PREC) ? 30720 : 26624;   // ring capacity, f32 entries (one workgroup per CU)
 };
 
 // ---- query-tile staging shared by both kernels ----------------------------------------------------------
@@ -33,9 +33,10 @@ template <int PREC, int THREADS, int NT = 1> struct QStage {
   int mul[NCH];             // bytes per query index step
   int dst[NCH];
   const float* cbase;       // wave 0: LSE row constants, wave 1: delta
+  float c_add;              // added to the (negated) row constant: fp16 mode's P scale exponent on the LSE seeds
 
   __device__ __forceinline__ void init(int tid, const char* Qh, const char* dOh, const char* Qth, const char* dOth,
-                                       const float* LSEh, const float* dlth, int Mp) {
+                                       const float* LSEh, const float* dlth, int Mp, float lse_add = 0.f) {
     static_assert(CH_ARR % 64 == 0, "a chunk slot's array must be wave-uniform");
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -55,12 +56,13 @@ template <int PREC, int THREADS, int NT = 1> struct QStage {
     }
     st_c = 0.f;
     cbase = (tid >> 6) == 0 ? LSEh : dlth;
+    c_add = (tid >> 6) == 0 ? lse_add : 0.f;
   }
   __device__ __forceinline__ void load(int tid, size_t mq0) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
       if (dst[c] >= 0) st[c] = *reinterpret_cast<const u32x4*>(base[c] + mq0 * mul[c] + off[c]);
-    if (tid < 128 && (tid & 63) < QTILE) st_c = -cbase[mq0 + (tid & 63)];   // negated: they seed the accumulators
+    if (tid < 128 && (tid & 63) < QTILE) st_c = c_add - cbase[mq0 + (tid & 63)];   // negated: they seed the accumulators
   }
   __device__ __forceinline__ void store(int tid, char* buf) {
 #pragma unroll

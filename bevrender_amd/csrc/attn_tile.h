@@ -29,7 +29,7 @@ struct KeyW {
 // Column capacity of the table regions, per precision mode and kernel (the LDS budgets are in the kernels).
 // The key-preparation kernel sizes the GROUPS of a half (below) for the smaller of the two.
 __host__ __device__ constexpr int region_cap_fwd(int prec) { return 88; }
-__host__ __device__ constexpr int region_cap_bwd_q(int prec) { return prec == BEVR_PREC_BF16 ? 56 : 48; }
+__host__ __device__ constexpr int region_cap_bwd_q(int prec) { return prec != BEVR_PREC_F32 ? 56 : 48; }
 __host__ __device__ constexpr int region_cap_min(int prec) {
   return region_cap_fwd(prec) < region_cap_bwd_q(prec) ? region_cap_fwd(prec) : region_cap_bwd_q(prec);
 }
@@ -106,22 +106,21 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 // per-(column, key) constants, written by the owning wave once per step (lane = key), read as a broadcast.
 // bf16 mode keeps only the packed bf16 tap weights (the gradient unpacks them: the weights the bias was computed
 // with); f32 mode keeps them in full precision.
-template <int PREC> struct ColKeyT;
-template <> struct ColKeyT<BEVR_PREC_BF16> {
+template <int PREC> struct ColKeyT {   // the 16-bit operand modes (bf16, fp16); f32 is specialised below
   // member order: the weights are one aligned 8-byte read (ds_read_b64, 2 clk) and the cell one 4-byte read; with the
   // cell first the compiler read the weights with ds_read2_b32 (4 clk)
-  unsigned wA, wB;  // tap weights of column x / x + 1 as packed bf16x2 (row y, row y + 1)
+  unsigned wA, wB;  // tap weights of column x / x + 1 as a packed 16-bit pair (row y, row y + 1)
   int cell;         // first tap's window position for lane row 0: cell index (backward) or byte offset (forward)
   unsigned pad;
   __device__ __forceinline__ void set(float w00, float w01, float w10, float w11) {
-    wA = pack_bf16x2(w00, w01);
-    wB = pack_bf16x2(w10, w11);
+    wA = Half<PREC>::pack2(w00, w01);
+    wB = Half<PREC>::pack2(w10, w11);
     pad = 0;
   }
-  __device__ __forceinline__ float w00() const { return __builtin_bit_cast(float, wA << 16); }
-  __device__ __forceinline__ float w01() const { return __builtin_bit_cast(float, wA & 0xffff0000u); }
-  __device__ __forceinline__ float w10() const { return __builtin_bit_cast(float, wB << 16); }
-  __device__ __forceinline__ float w11() const { return __builtin_bit_cast(float, wB & 0xffff0000u); }
+  __device__ __forceinline__ float w00() const { return Half<PREC>::lo(wA); }
+  __device__ __forceinline__ float w01() const { return Half<PREC>::hi(wA); }
+  __device__ __forceinline__ float w10() const { return Half<PREC>::lo(wB); }
+  __device__ __forceinline__ float w11() const { return Half<PREC>::hi(wB); }
 };
 template <> struct ColKeyT<BEVR_PREC_F32> {
   int cell;

@@ -8,6 +8,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
@@ -37,6 +39,44 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 template <int PREC> struct Elem;
 template <> struct Elem<BEVR_PREC_F32> { typedef float type; static constexpr int bytes = 4; };
 template <> struct Elem<BEVR_PREC_BF16> { typedef __bf16 type; static constexpr int bytes = 2; };
+template <> struct Elem<BEVR_PREC_F16> { typedef _Float16 type; static constexpr int bytes = 2; };
+
+// the two 16-bit operand modes share every layout and all storage (kept as raw bits in bf16x8 / uint32 registers); what
+// differs is the arithmetic on the bits
+__host__ __device__ constexpr bool is16(int prec) { return prec != BEVR_PREC_F32; }
+template <int PREC> struct Half;
+template <> struct Half<BEVR_PREC_BF16> {
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+  static __device__ __forceinline__ float lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+  static __device__ __forceinline__ float hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+  }
+  static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+  static constexpr float NEG_BIG = -1.0e30f;   // "masked" entry of a 16-bit table window
+  static constexpr float SHIFT = 0.f;          // binades between the forward's softmax reference and the running maximum
+};
+template <> struct Half<BEVR_PREC_F16> {
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, f16x2));   // v_cvt_pk_f16_f32, nearest even
+  }
+  static __device__ __forceinline__ float lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+  static __device__ __forceinline__ float hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+  static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b), c, false);
+  }
+  static __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+  // fp16 cannot hold -1e30 (it would become -inf, and -inf times a zero tap weight is NaN): any value whose exp2 is 0
+  static constexpr float NEG_BIG = -60000.0f;
+  // fp16's normal range ends at 2^-14: the forward keeps its reference 10 binades under the running maximum, so that
+  // softmax weights down to 2^-24 of the largest are normal numbers (they may reach 2^12; fp16 holds 2^15)
+  static constexpr float SHIFT = 10.f;
+};
 
 // A or B operand fragment of one 32-wide tile with the 32-deep contraction held by this lane:
 //   bf16: 2 k-steps x 8 elements  (element j of step s <-> contraction index 16 s + 8 hi + j)
@@ -54,6 +94,7 @@ template <> struct Frag<BEVR_PREC_BF16> {
     v[1] = __builtin_bit_cast(bf16x8, b);
   }
 };
+template <> struct Frag<BEVR_PREC_F16> : Frag<BEVR_PREC_BF16> {};   // same bits, same loads
 template <> struct Frag<BEVR_PREC_F32> {
   float v[16];
   __device__ __forceinline__ void load(const void* row, int hi) {
@@ -71,6 +112,11 @@ template <> struct Frag<BEVR_PREC_F32> {
 __device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_BF16>& a, const Frag<BEVR_PREC_BF16>& b, f32x16 acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[0], b.v[0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v[1], b.v[1], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_F16>& a, const Frag<BEVR_PREC_F16>& b, f32x16 acc) {
+  acc = Half<BEVR_PREC_F16>::mfma(a.v[0], b.v[0], acc);
+  acc = Half<BEVR_PREC_F16>::mfma(a.v[1], b.v[1], acc);
   return acc;
 }
 __device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_F32>& a, const Frag<BEVR_PREC_F32>& b, f32x16 acc) {
@@ -93,6 +139,16 @@ __device__ __forceinline__ f32x16 mma_acc_b(const Frag<BEVR_PREC_BF16>& a, const
   }
   return acc;
 }
+__device__ __forceinline__ f32x16 mma_acc_b(const Frag<BEVR_PREC_F16>& a, const f32x16& x, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    u32x4 w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = Half<BEVR_PREC_F16>::pack2(x[8 * s + 2 * k], x[8 * s + 2 * k + 1]);
+    acc = Half<BEVR_PREC_F16>::mfma(a.v[s], __builtin_bit_cast(bf16x8, w), acc);
+  }
+  return acc;
+}
 __device__ __forceinline__ f32x16 mma_acc_b(const Frag<BEVR_PREC_F32>& a, const f32x16& x, f32x16 acc) {
   // memory order perm32: fragment element t (within this lane-half's 16) sits at position
   // 16 (t >> 3) + 8 hi + (t & 7) of the 32-block; Frag::load read positions 16 hi .. 16 hi + 15, which is
@@ -104,6 +160,7 @@ __device__ __forceinline__ f32x16 mma_acc_b(const Frag<BEVR_PREC_F32>& a, const 
 
 // Load an A fragment for mma_acc_b from a 32-block stored in perm32 order.
 __device__ __forceinline__ void load_perm(Frag<BEVR_PREC_BF16>& f, const void* row, int hi) { f.load(row, hi); }
+__device__ __forceinline__ void load_perm(Frag<BEVR_PREC_F16>& f, const void* row, int hi) { f.load(row, hi); }
 __device__ __forceinline__ void load_perm(Frag<BEVR_PREC_F32>& f, const void* row, int hi) {
   // wanted: contraction row crow(t, hi) = 8 (t>>2) + 4 hi + (t&3); its perm32 position is
   // 16 (t>>3) + 8 hi + (t & 7).
@@ -148,7 +205,8 @@ static inline int bevr_check_desc(const bevr_attn_desc* d) {
   bevr_attn_desc t = *d;
   if (bevr_attn_table_dims(&t) != 0) return BEVR_E_SHAPE;
   if (t.Hp != d->Hp || t.Wp != d->Wp || t.y_off != d->y_off || t.x_off != d->x_off) return BEVR_E_SHAPE;
-  if (d->precision != BEVR_PREC_F32 && d->precision != BEVR_PREC_BF16) return BEVR_E_PRECISION;
+  if (d->precision != BEVR_PREC_F32 && d->precision != BEVR_PREC_BF16 && d->precision != BEVR_PREC_F16)
+    return BEVR_E_PRECISION;
   // 32-bit byte offsets into one head's pair table
   if ((long long)d->Hp * d->Wp * 8 >= (1LL << 31)) return BEVR_E_SHAPE;
   return BEVR_OK;

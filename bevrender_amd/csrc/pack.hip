@@ -21,6 +21,10 @@ template <> __device__ __forceinline__ float to_elem<float>(float x) { return x;
 template <> __device__ __forceinline__ unsigned short to_elem<unsigned short>(float x) {
   return (unsigned short)(pack_bf16x2(x, 0.f) & 0xffffu);   // round to nearest even, as torch's .to(bfloat16)
 }
+struct half_bits { unsigned short u; };   // fp16 element (same size and layouts as bf16; distinct type for to_elem)
+template <> __device__ __forceinline__ half_bits to_elem<half_bits>(float x) {
+  return half_bits{(unsigned short)(Half<BEVR_PREC_F16>::pack2(x, 0.f) & 0xffffu)};   // nearest even, as .to(float16)
+}
 
 // One workgroup = 64 consecutive keys of one problem, all heads, K and V.
 template <typename E>
@@ -109,15 +113,18 @@ extern "C" int bevr_pack_kv(const float* k, const float* v, long long ld, long l
   if (n_prob <= 0 || N <= 0 || Np < N || Np % PK || heads <= 0 || c <= 0 || c > 32 || ld < (long long)heads * c ||
       pstride < N)
     return BEVR_E_SHAPE;
-  if (precision != BEVR_PREC_BF16 && precision != BEVR_PREC_F32) return BEVR_E_PRECISION;
+  if (precision != BEVR_PREC_BF16 && precision != BEVR_PREC_F32 && precision != BEVR_PREC_F16) return BEVR_E_PRECISION;
   if (!bevr_aligned16(Kr) || !bevr_aligned16(Vr) || (Kt && !bevr_aligned16(Kt)) || (Vt && !bevr_aligned16(Vt)))
     return BEVR_E_ALIGN;
-  const size_t eb = precision == BEVR_PREC_BF16 ? 2 : 4;
+  const size_t eb = precision == BEVR_PREC_F32 ? 4 : 2;
   const int hg = (int)(32768 / (2 * PK * 32 * eb));
   const dim3 grid(Np / PK, n_prob, (heads + hg - 1) / hg);
   const size_t lds = (size_t)2 * (heads < hg ? heads : hg) * PK * 32 * eb;
   hipStream_t st = (hipStream_t)stream;
-  if (precision == BEVR_PREC_BF16)
+  if (precision == BEVR_PREC_F16)
+    hipLaunchKernelGGL(pack_kv_kernel<half_bits>, grid, dim3(256), lds, st, k, v, ld, pstride, N, Np, heads, c,
+                       (half_bits*)Kr, (half_bits*)Vr, (half_bits*)Kt, (half_bits*)Vt);
+  else if (precision == BEVR_PREC_BF16)
     hipLaunchKernelGGL(pack_kv_kernel<unsigned short>, grid, dim3(256), lds, st, k, v, ld, pstride, N, Np, heads, c,
                        (unsigned short*)Kr, (unsigned short*)Vr, (unsigned short*)Kt, (unsigned short*)Vt);
   else

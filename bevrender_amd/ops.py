@@ -256,7 +256,7 @@ KERNEL_TIMER = _KernelTimer()
 
 
 def _edtype(precision: int):
-    return torch.bfloat16 if precision == _lib.PREC_BF16 else torch.float32
+    return {_lib.PREC_BF16: torch.bfloat16, _lib.PREC_F16: torch.float16}.get(precision, torch.float32)
 
 
 def _perm_t(x: torch.Tensor) -> torch.Tensor:
@@ -365,6 +365,13 @@ class _AttnCore(torch.autograd.Function):
         L = _lib.lib()
         ed = _edtype(geom.precision)
         dO = dO.contiguous()
+        f16 = geom.precision == _lib.PREC_F16
+        if f16:
+            # fp16 has 5 exponent bits and the reference trains without a loss scaler: a cotangent of a mean-type loss
+            # (~1e-7 per element) would fall into fp16's subnormals.  Every gradient is linear in dO, so the cotangent is
+            # brought to ~2^10 with a power of two (exact) here and the gradients are scaled back below.  No host sync.
+            sdo = torch.exp2(torch.floor(10.0 - torch.log2(dO.abs().max().clamp_min(1e-30))))
+            dO = dO * sdo
         dOe = dO.to(ed).contiguous()
         # delta = rowsum(dO o O) from the SAME (rounded) dO the kernels contract with V for dP: dS = P (dP - delta) then
         # cancels as it must where P -> 1 (with the f32 dO here and the bf16 one there, |dS| kept a floor of
@@ -379,6 +386,26 @@ class _AttnCore(torch.autograd.Function):
         dOt = _perm_t(dOe)
         N, C2 = ctx.kv_shape[1], ctx.kv_shape[-1]
         dkv = torch.empty(ctx.kv_shape, device=dev, dtype=torch.float32)
+        # Scales of the backward kernels (include/bevrender_hip.h, grad_scale[8]); powers of two, on the device, no sync.
+        # bound >= |dP - delta| of every pair: |dP| = |dO_q . V_n| <= ||dO_q|| ||V_n||; Pmax = the largest softmax weight of
+        # the launch (forward, LSE plane 1; +0.05 in log2 for the rounding of the recomputed logits) -- with 10^5 keys
+        # per row Pmax is far below 1.
+        #   [0], [1]  s, 1/s with s Pmax bound <= 2^30: unit of bwd_q's fixed-point table-gradient cells (it applies s to
+        #             dO and delta as it loads them -- exact -- and ln2 / s when it stores);
+        #   fp16 only: [2] kp with Pmax 2^kp <= 2^14 (softmax weights as fp16 operands), [3] c2 with
+        #             Pmax bound 2^kp c2 <= 2^14 (logit gradients as fp16 operands), [4], [5] the inverses; s = 2^16 2^kp c2.
+        vmax = torch.stack([saved[6 * i + 1].float().norm(dim=-1).max() for i in range(len(ctx.segs))]).max()
+        bound = (dOe.float().norm(dim=-1).max() * vmax + delta.abs().max()).clamp_min(1e-30)
+        pmax_log2 = (LSE[1].max() + 0.05).clamp(-60.0, 0.0)
+        zero, one = torch.zeros((), device=dev), torch.ones((), device=dev)
+        if f16:
+            kp = torch.floor(14.0 - pmax_log2)
+            e16 = torch.floor(14.0 - torch.log2(bound) - pmax_log2).clamp(-100.0, 100.0)
+            gscale = torch.stack((torch.exp2(e16 + 16.0), torch.exp2(-e16 - 16.0), kp, torch.exp2(e16 - kp),
+                                  torch.exp2(-e16), torch.exp2(-kp), zero, zero)).float().contiguous()
+        else:
+            e = torch.floor(30.0 - torch.log2(bound) - pmax_log2).clamp(-100.0, 100.0)
+            gscale = torch.stack((torch.exp2(e), torch.exp2(-e), zero, one, one, one, zero, zero)).float().contiguous()
         das, dbs = [], []
         for i, sg in enumerate(ctx.segs):
             g = sg.geom
@@ -387,19 +414,9 @@ class _AttnCore(torch.autograd.Function):
             if sg.cell:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_cell_bwd_q", _attn_flops(g, 3), L.bevr_attn_cell_bwd_q, C.byref(d),
                                             _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
-                                            _ptr(LSE), _ptr(delta), _ptr(dQ), _ptr(dT), _stream()),
+                                            _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream()),
                            "bevr_attn_cell_bwd_q")
             else:
-                # fixed-point scale of the in-LDS table-gradient accumulation (include/bevrender_hip.h): a power of two s
-                # with s * bound <= 2^30, bound >= |P (dP - delta)| of every pair: |dP| = |dO_q . V_n| <= ||dO_q|| ||V_n||,
-                # and P <= Pmax, the largest softmax weight of the launch (forward, LSE plane 1; +0.05 in log2 for the
-                # rounding of the recomputed logits) -- with 10^5 keys per row Pmax is far below 1, and the unit that much
-                # finer.  The kernel applies s to dO and delta as it loads them (exact: a power of two) and ln2 / s when
-                # it stores.  Stays on the device (no sync).
-                bound = dOe.float().norm(dim=-1).max() * Ve.float().norm(dim=-1).max() + delta.abs().max()
-                pmax_log2 = (LSE[1].max() + 0.05).clamp(-60.0, 0.0)
-                e = torch.floor(30.0 - torch.log2(bound.clamp_min(1e-30)) - pmax_log2).clamp(-100.0, 100.0)
-                gscale = torch.stack((torch.exp2(e), torch.exp2(-e))).contiguous()
                 _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(g, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
                                             _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
                                             _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream()),
@@ -412,13 +429,13 @@ class _AttnCore(torch.autograd.Function):
             if sg.cell:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_cell_bwd_k", _attn_flops(g, 4), L.bevr_attn_cell_bwd_k, C.byref(d),
                                             _ptr(Qe), _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
-                                            _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(dK), _ptr(dV), _ptr(da), _ptr(db),
-                                            _stream()), "bevr_attn_cell_bwd_k")
+                                            _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dK), _ptr(dV),
+                                            _ptr(da), _ptr(db), _stream()), "bevr_attn_cell_bwd_k")
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_k", _attn_flops(g, 4), L.bevr_attn_bwd_k, C.byref(d), _ptr(Qe),
                                             _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(ka), _ptr(kb), _ptr(pair), _ptr(dOe),
-                                            _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(dK), _ptr(dV), _ptr(da), _ptr(db),
-                                            _stream()), "bevr_attn_bwd_k")
+                                            _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dK), _ptr(dV),
+                                            _ptr(da), _ptr(db), _stream()), "bevr_attn_bwd_k")
             # gradients of the row layout back to K | V rows (the adjoint of the packing), into the segment's rows
             kp = dkv.data_ptr() + sg.n0 * C2 * 4
             _lib.check(L.bevr_unpack_dkv(_ptr(dK), _ptr(dV), C.c_void_p(kp), C.c_void_p(kp + 2 * C2), C2, N, g.n_prob,
@@ -429,6 +446,9 @@ class _AttnCore(torch.autograd.Function):
             dQ = dQ.reshape(geom.n_prob // geom.q_div, geom.q_div, geom.heads, geom.Mp, HEAD_DIM).sum(1)
         da = das[0] if len(das) == 1 else torch.cat(das, 1)
         db = dbs[0] if len(dbs) == 1 else torch.cat(dbs, 1)
+        if f16:   # undo the cotangent's power-of-two scale
+            inv = 1.0 / sdo
+            dQ, dkv, da, db, dT = dQ * inv, dkv * inv, da * inv, db * inv, dT * inv
         return dQ, dkv, da, db, dT, None, None
 
 

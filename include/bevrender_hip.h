@@ -39,7 +39,7 @@ extern "C" {
 
 /* 3: bevr_attn_fwd writes TWO LSE planes (round 2 changed that under version 2: a version-2 caller's [n_prob][heads][Mp]
  *    buffer is too small), the key workspace carries group boxes, bevr_attn_bwd_q takes grad_scale; new: bevr_attn_cell_*,
- *    problem strides of bevr_pack_kv / bevr_unpack_dkv. */
+ *    problem strides of bevr_pack_kv / bevr_unpack_dkv, BEVR_PREC_F16, grad_scale[8] for every backward entry point. */
 #define BEVR_ABI_VERSION 3
 
 enum {
@@ -50,7 +50,10 @@ enum {
   BEVR_E_ALIGN = -4      /* a pointer is not 16-byte aligned */
 };
 
-enum { BEVR_PREC_F32 = 0, BEVR_PREC_BF16 = 1 };
+/* BEVR_PREC_F16: fp16 operands (v_mfma_f32_32x32x16_f16), f32 accumulate -- BASELINE config 5.  fp16 has 5 exponent bits:
+ * the kernels keep softmax weights and logit gradients inside its normal range with power-of-two scales (forward: the
+ * softmax reference sits 10 binades below the running maximum; backward: grad_scale[2..5]). */
+enum { BEVR_PREC_F32 = 0, BEVR_PREC_BF16 = 1, BEVR_PREC_F16 = 2 };
 
 int bevr_abi_version(void);
 /* Human-readable text for a BEVR_E_* code (static storage). */
@@ -90,7 +93,7 @@ typedef struct bevr_attn_desc {
   int32_t Ht, Wt;    /* rpe table height (must equal 2S-1) and width                         */
   int32_t Hp, Wp;    /* padded table dims                                                    */
   int32_t y_off, x_off;
-  int32_t precision; /* BEVR_PREC_F32: exact-f32 MFMA; BEVR_PREC_BF16: bf16 operands, f32 accumulate */
+  int32_t precision; /* BEVR_PREC_F32: exact-f32 MFMA; BEVR_PREC_BF16 / BEVR_PREC_F16: 16-bit operands, f32 accumulate */
   int32_t reserved;
 } bevr_attn_desc;
 
@@ -107,7 +110,7 @@ int bevr_attn_table_dims(bevr_attn_desc* d);
 size_t bevr_attn_key_ws_bytes(const bevr_attn_desc* d);
 int bevr_attn_key_prep(const bevr_attn_desc* d, const float* key_a, const float* key_b, void* key_ws, void* stream);
 
-/* Forward.  Element type E = float (F32) or bf16 (BF16).
+/* Forward.  Element type E = float (F32), bf16 (BF16) or fp16 (F16).
  *   Q   [n_prob/q_div][heads][Mp][32]  E     K  [n_prob][heads][Np][32] E
  *   Vt  [n_prob][heads][32][Np] E, keys permuted inside each aligned block of 32: the key with
  *       in-block index r is stored at position (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1)
@@ -126,13 +129,19 @@ int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const v
  *   it is ACCUMULATED into (caller zeroes it).
  *   V  [n_prob][heads][Np][32] E (row layout), Kt [like Vt] E, dO [n_prob][heads][Mp][32] E,
  *   delta [n_prob][heads][Mp] float = rowsum(dO * O).
- *   grad_scale [2] float (device): { s, 1/s } with s a power of two such that s * max|P (dP - delta)| <= 2^30; a
+ *   grad_scale [8] float (device): { s, 1/s, kp, c2, 1/(2^kp c2), 2^-kp, 0, 0 }.  s: a power of two such that s * max|P (dP - delta)| <= 2^30; a
  *   valid bound is Pmax * (max_q |dO_q| * max_n |V_n| + max |delta|) (Euclidean norms over the 32 channels), Pmax = 1
  *   or the largest softmax weight of the launch (2^max of LSE plane 1, with a margin for the recomputation).  The
  *   kernel multiplies dO and delta by s as it loads them (exact) and accumulates the table gradient in 64-bit fixed
  *   point with unit ln2 / s (each contribution rounded to nearest; sums are exact and order-independent within a
  *   workgroup's window, and a cell cannot wrap: 2^33 contributions of the largest size fit); ln2 / s is applied
  *   when a cell is flushed and when dQ is stored.
+ *   Entries 2..5 are read in BEVR_PREC_F16 mode only, by every backward entry point (the others take the same array
+ *   and ignore it in the other modes): kp, an integer-valued exponent with Pmax 2^kp <= 2^14 -- the kernels form
+ *   P' = P 2^kp so that fp16 holds the softmax weights in its normal range; c2, a power of two with
+ *   max|P' (dP - delta) c2| <= 2^14 -- the logit gradient as fp16 operand; then their inverses.  bevr_attn_bwd_q
+ *   additionally needs s = 2^16 2^kp c2 there (its fixed-point cells then count units of 2^-16 of an fp16 operand,
+ *   and s max|P (dP - delta)| <= 2^30 as in the other modes); dO and delta are NOT pre-scaled by s in this mode.
  *   All gradients are with respect to the log2-domain logits' inputs as handed in (Q pre-scaled,
  *   table pre-multiplied): the caller's autograd undoes the scaling. */
 int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
@@ -145,7 +154,7 @@ int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const
  *   Qt, dOt: [..][heads][32][Mp] E with the same in-32 permutation as Vt (over the packed query index). */
 int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
                     const float* key_a, const float* key_b, const float* table_pair,
-                    const void* dO, const void* dOt, const float* LSE, const float* delta,
+                    const void* dO, const void* dOt, const float* LSE, const float* delta, const float* grad_scale,
                     float* dK, float* dV, float* dkey_a, float* dkey_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -167,12 +176,12 @@ int bevr_attn_cell_fwd(const bevr_attn_desc* d, const void* Q, const void* K, co
                        float* O, float* LSE, void* stream);
 int bevr_attn_cell_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
                          const void* key_ws, const float* table_pair, const void* dO, const float* LSE,
-                         const float* delta, float* dQ, float* dtable, void* stream);
+                         const float* delta, const float* grad_scale, float* dQ, float* dtable, void* stream);
 /* dK, dV written; dkey_a, dkey_b ACCUMULATED (as bevr_attn_bwd_k). */
 int bevr_attn_cell_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
                          const void* key_ws, const float* table_pair, const void* dO, const void* dOt,
-                         const float* LSE, const float* delta, float* dK, float* dV, float* dkey_a, float* dkey_b,
-                         void* stream);
+                         const float* LSE, const float* delta, const float* grad_scale, float* dK, float* dV,
+                         float* dkey_a, float* dkey_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bilinear feature sampling, align_corners=True, zero padding (grid_sample semantics).
@@ -238,7 +247,7 @@ int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
  *         and problem stride pstride ROWS (pstride >= N; a key segment of a longer row array: pstride = its row count)
  *   Kr, Vr [n_prob][heads][Np][32] E   row layout: head_dim c <= 32 zero padded, keys N..Np-1 zero (Np % 64 == 0)
  *   Kt, Vt [n_prob][heads][32][Np] E   transposed, bits 2 <-> 3 of the in-32 key index swapped (either may be NULL)
- *   E = bf16 (BEVR_PREC_BF16, round to nearest even) or float (BEVR_PREC_F32).
+ *   E = bf16 (BEVR_PREC_BF16) or fp16 (BEVR_PREC_F16), round to nearest even, or float (BEVR_PREC_F32).
  * bevr_unpack_dkv is the adjoint on the gradients of the row layout: dK, dV [n_prob][heads][Np][32] float ->
  * dk, dv rows (n_prob, N, heads*c) with row stride ld (every element of the rows written).
  * ---------------------------------------------------------------------------------------------- */

@@ -16,7 +16,10 @@ DEV = "cuda"
 
 # tolerances: F32 = exact-f32 MFMA, differences are summation order + the algebraic bias reformulation;
 # BF16 = bf16 operands (Q, K, V, P, dO, dS), f32 accumulation.
-TOL = {_lib.PREC_F32: dict(rtol=2e-4, atol=2e-5), _lib.PREC_BF16: dict(rtol=3e-2, atol=1.5e-2)}
+# F16 = fp16 operands (11-bit significand against bf16's 8): its limits sit between the two.
+TOL = {_lib.PREC_F32: dict(rtol=2e-4, atol=2e-5), _lib.PREC_BF16: dict(rtol=3e-2, atol=1.5e-2),
+       _lib.PREC_F16: dict(rtol=6e-3, atol=3e-3)}
+GRAD_LIM = {_lib.PREC_F32: 5e-4, _lib.PREC_BF16: 3e-2, _lib.PREC_F16: 6e-3}
 
 
 def rel_err(got, want):
@@ -61,7 +64,7 @@ CORE_CFGS = [
 ]
 
 
-@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16])
+@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16, _lib.PREC_F16])
 @pytest.mark.parametrize("cfg", CORE_CFGS)
 def test_attention_core_forward_backward(cfg, prec):
     B, V, C, h, g, S, D, N = cfg
@@ -78,7 +81,7 @@ def test_attention_core_forward_backward(cfg, prec):
     got.backward(cot.to(DEV))
     torch.cuda.synchronize()
     names = ["query", "k", "v", "pos", "table"]
-    lim = 5e-4 if prec == _lib.PREC_F32 else 3e-2
+    lim = GRAD_LIM[prec]
     for n, a, b in zip(names, ins_gpu, ins_cpu):
         e = rel_err(a.grad.cpu(), b.grad)
         assert e < lim, f"grad {n}: rel err {e:.3e}"

@@ -19,6 +19,10 @@
 #include "attn_cell.h"
 #include "attn_kstage.h"
 
+#ifndef BEVR_VARIANT
+#define BEVR_VARIANT 0
+#endif
+
 namespace {
 
 constexpr int TWC = 768;             // 12 waves x 32 keys, 3 waves per SIMD: one workgroup per CU
@@ -206,10 +210,13 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
       }
       // table operand of this (column, row block), lane = BEV row rb * 32 + lq: requested first, consumed after the
       // S and dP products (global loads served by L1 / L2: the waves of the workgroup sit in the same cells)
-      // table operand of this (column, row block), lane = BEV row rb * 32 + lq: requested first, consumed after the S and
-      // dP products (global loads served by L1 / L2: the waves of the workgroup sit in the same cells).  Requesting it one
-      // tile ahead was tried: 8 more live registers, 11 spills, 28.5 -> 36.6 ms.
-      if constexpr (!SLOW) load_raw(traw, rb);
+      // table operand of this (column, row block), lane = BEV row rb * 32 + lq (global loads served by L1 / L2: the waves of
+      // the workgroup sit in the same cells).  Its raw entries live in `traw`; the NEXT row block's are requested into the
+      // same registers at the END of this tile (below), so only a column's first row block waits for its
+      // loads.  (A second set of registers for the prefetch: 11 spills, 28.5 -> 36.6 ms.  Without the table loads: -15 %.)
+      if constexpr (!SLOW) {
+        if (rb == 0) load_raw(traw, 0);   // later row blocks: requested during the previous tile, see below
+      }
       const f32x4* rc = reinterpret_cast<const f32x4*>(base + 2 * L::TILE_Q + 2 * L::TILE_T);
       f32x16 s, dp;
       {
@@ -308,6 +315,11 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
         Frag<PREC> qtf;
         load_perm(qtf, base + 2 * L::TILE_Q + lq * L::TSTRIDE, hi);
         dk = mma_acc_b(qtf, dp, dk);
+      }
+      // the next row block's table entries, requested at the tile's end (register pressure is past its peak) and consumed
+      // in the middle of the next tile
+      if constexpr (!SLOW) {
+        if (rb + 1 < n_rb) load_raw(traw, rb + 1);
       }
     }
 

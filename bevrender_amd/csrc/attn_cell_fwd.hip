@@ -27,9 +27,6 @@
 #include <type_traits>
 #include "attn_cell.h"
 
-#ifndef BEVR_VARIANT
-#define BEVR_VARIANT 0
-#endif
 
 namespace {
 
@@ -178,10 +175,6 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     }
   };
 
-#if BEVR_VARIANT & 1
-  Frag<PREC> qreg;
-  load_q(qreg);
-#endif
   // ---- online-softmax state --------------------------------------------------------------------------
   f32x16 o;
   float m = 0.f, l = 0.f;
@@ -210,25 +203,11 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
   }
 
-  // ---- one tile: S^T = K Q^T (+ bias), P = exp2(S^T - m), l += sum P, o += V^T P^T -----------------------------
-  CellFrag<PREC> tf;          // table operand of the chunk this wave holds, and its origin
-  int tag_x = 1 << 30, tag_a = 1 << 30;
-  if constexpr (is16(PREC)) tf.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) tf.v[k] = 0.f;
-  }
+  // ---- one tile of the slow pass: S^T = K Q^T + gathered bias, P = exp2(S^T - m), l += sum P, o += V^T P^T -----------
   // MASKED: the tile may hold padded keys (last step only).  A separate instantiation: inside one body the compiler
   // hoisted the 16 key-index compares out of the `last step` branch and every tile paid 32 instructions for them.
-  auto tile = [&](auto masked_tag, const char* base, int step, int t, int x0, int a0) {
+  auto tile = [&](auto masked_tag, const char* base, int step, int t) {
     constexpr bool MASKED = decltype(masked_tag)::value;
-    if constexpr (!SLOW) {
-      if (x0 != tag_x || a0 != tag_a) {   // uniform: new chunk origin
-        tf = cell_table<PREC>(tbl, d, x0, a0 + i0 + lq, hi);
-        tag_x = x0;
-        tag_a = a0;
-      }
-    }
 #pragma unroll 1
     for (int attempt = 0; attempt < 2; ++attempt) {
       f32x16 s;
@@ -237,26 +216,11 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
       {
         Frag<PREC> kf;
         kf.load(base + (t * 32 + lq) * L::K_STRIDE, hi);
-#if BEVR_VARIANT & 1
-        s = mma_frag(kf, qreg, s);
-#else
         Frag<PREC> qf;
         load_q(qf);
         s = mma_frag(kf, qf, s);   // S^T[key][query]
-#endif
       }
-      if constexpr (!SLOW) {
-        CellFrag<PREC> wf;
-        const char* wsrc = base + L::OFF_W + (t * 64 + lane) * L::WL;
-        if constexpr (is16(PREC)) {
-          wf.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc));
-        } else {
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc), w1 = *reinterpret_cast<const f32x4*>(wsrc + 16);
-          wf.v[0] = w0[0]; wf.v[1] = w0[1]; wf.v[2] = w0[2]; wf.v[3] = w0[3];
-          wf.v[4] = w1[0]; wf.v[5] = w1[1]; wf.v[6] = w1[2]; wf.v[7] = w1[3];
-        }
-        s = mma_cell(wf, tf, s);   // + bias^T[key][query]
-      } else {
+      {
         // per-pair gather from the table in global memory (any key set)
         const KeyW* kwl = reinterpret_cast<const KeyW*>(base + L::OFF_KW);
         const int rowoff = (i0 + lq) * 8;
@@ -298,11 +262,7 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const f32x2 sh = f32x2{s[r], s[r + 1]} + nm;
-#if BEVR_VARIANT & 16
-        const f32x2 pp = sh * sh;            // timing experiment only: no exp
-#else
         const f32x2 pp = {fast_exp2(sh[0]), fast_exp2(sh[1])};
-#endif
         s[r] = pp[0];
         s[r + 1] = pp[1];
         ls2 += pp;
@@ -314,6 +274,131 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
         Frag<PREC> vf;
         load_perm(vf, base + L::OFF_V + lq * L::V_STRIDE + t * 32 * EB, hi);
         o = mma_acc_b(vf, s, o);
+      }
+      if (__any(ts > mass_thr<PREC>())) {   // wave-uniform, rare: keep every committed weight <= mass_thr of the reference
+        const float tb = ts + __shfl_xor(ts, 32);
+        const float up = fmaxf(ceilf(__log2f(tb)) - shift16<PREC>(), 0.f);
+        const float al = fast_exp2(-up);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= al;
+        l *= al;
+        m += up;
+      }
+      break;
+    }
+  };
+
+
+  // ---- the two tiles of a step of the fast pass in ONE straight-line body.  A wave parks ~2/3 of its time on the serial
+  // chain LDS -> 3 MFMAs -> exp -> sum -> LDS -> 2 MFMAs of a tile (PMC: profiles/r03_pmc_*; exp, barrier, staging each
+  // cost < 10 %); two independent chains let the second tile's MFMAs run under the first one's exponentials.  A tile
+  // that is dead or left to the slow pass (ok = 0) gets weight 0.  One body for every case: a second, per-tile body for
+  // the rare cases next to this one cost the loop 130 B of spills per lane (22 -> 43 ms).
+  CellFrag<PREC> tf0, tf1;    // table operands of the chunks of tile 0 / 1, and their origins
+  int tag_x0 = 1 << 30, tag_a0 = 1 << 30, tag_x1 = 1 << 30, tag_a1 = 1 << 30;
+  if constexpr (is16(PREC)) {
+    tf0.v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    tf1.v = tf0.v;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { tf0.v[k] = 0.f; tf1.v[k] = 0.f; }
+  }
+  auto load_w = [&](CellFrag<PREC>& wf, const char* wsrc) {
+    if constexpr (is16(PREC)) {
+      wf.v = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wsrc));
+    } else {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wsrc), w1 = *reinterpret_cast<const f32x4*>(wsrc + 16);
+      wf.v[0] = w0[0]; wf.v[1] = w0[1]; wf.v[2] = w0[2]; wf.v[3] = w0[3];
+      wf.v[4] = w1[0]; wf.v[5] = w1[1]; wf.v[6] = w1[2]; wf.v[7] = w1[3];
+    }
+  };
+  auto tile2 = [&](auto masked_tag, const char* base, int step, int ok0, int ok1, int x00, int a00, int x01, int a01) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    if (ok0 && (x00 != tag_x0 || a00 != tag_a0)) {   // uniform: new chunk origin
+      tf0 = cell_table<PREC>(tbl, d, x00, a00 + i0 + lq, hi);
+      tag_x0 = x00;
+      tag_a0 = a00;
+    }
+    if (ok1 && (x01 != tag_x1 || a01 != tag_a1)) {
+      tf1 = cell_table<PREC>(tbl, d, x01, a01 + i0 + lq, hi);
+      tag_x1 = x01;
+      tag_a1 = a01;
+    }
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }   // literal-zero accumulators: no register splat
+      {
+        Frag<PREC> k0, k1, qf;
+        k0.load(base + lq * L::K_STRIDE, hi);
+        k1.load(base + (32 + lq) * L::K_STRIDE, hi);
+        load_q(qf);
+        s0 = mma_frag(k0, qf, s0);   // S^T[key][query]
+        s1 = mma_frag(k1, qf, s1);
+      }
+      {
+        CellFrag<PREC> w0, w1;
+        load_w(w0, base + L::OFF_W + lane * L::WL);
+        load_w(w1, base + L::OFF_W + (64 + lane) * L::WL);
+        s0 = mma_cell(w0, tf0, s0);   // + bias^T[key][query]
+        s1 = mma_cell(w1, tf1, s1);
+      }
+      if (!ok0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = BEVR_NEG_BIG;
+      }
+      if (!ok1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[r] = BEVR_NEG_BIG;
+      }
+      if constexpr (MASKED) {   // padded keys: no weight
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] = (step * KT + crow(r, hi) >= d.N) ? BEVR_NEG_BIG : s0[r];
+          s1[r] = (step * KT + 32 + crow(r, hi) >= d.N) ? BEVR_NEG_BIG : s1[r];
+        }
+      }
+      if (first || attempt == 1) {   // exact maximum of the step: sets / moves the reference before the weights are formed
+        float tm = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, fmaxf(s0[r], s1[r]));
+        tm = fmaxf(tm, __shfl_xor(tm, 32)) - shift16<PREC>();   // the lane halves hold the same queries, different keys
+        const float mn = first ? tm : fmaxf(m, tm);
+        const float al = first ? 0.f : fast_exp2(m - mn);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= al;
+        l *= al;
+        m = mn;
+        first = false;
+      }
+      const f32x2 nm = {-m, -m};
+      f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sh = f32x2{s0[r], s0[r + 1]} + nm;
+        const f32x2 pp = {fast_exp2(sh[0]), fast_exp2(sh[1])};
+        s0[r] = pp[0];
+        s0[r + 1] = pp[1];
+        ls2 += pp;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sh = f32x2{s1[r], s1[r + 1]} + nm;
+        const f32x2 pp = {fast_exp2(sh[0]), fast_exp2(sh[1])};
+        s1[r] = pp[0];
+        s1[r + 1] = pp[1];
+        ls2 += pp;
+      }
+      const float ts = ls2[0] + ls2[1];
+      if (attempt == 0 && __any(!(ts <= mass_redo<PREC>()))) continue;   // overflowed against the old reference: redo exactly
+      l += ts;
+      {
+        Frag<PREC> v0, v1;
+        load_perm(v0, base + L::OFF_V + lq * L::V_STRIDE, hi);
+        load_perm(v1, base + L::OFF_V + lq * L::V_STRIDE + 32 * EB, hi);
+        o = mma_acc_b(v0, s0, o);
+        o = mma_acc_b(v1, s1, o);
       }
       if (__any(ts > mass_thr<PREC>())) {   // wave-uniform, rare: keep every committed weight <= mass_thr of the reference
         const float tb = ts + __shfl_xor(ts, 32);
@@ -359,8 +444,8 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
       __syncthreads();                  // every wave is done with the previous tile's buffer
       stage_direct(smem, step, tid);
       __syncthreads();
-      if (step == n_step - 1 && d.N < d.Np) tile(std::true_type{}, smem, step, t, 0, 0);
-      else tile(std::false_type{}, smem, step, t, 0, 0);
+      if (step == n_step - 1 && d.N < d.Np) tile(std::true_type{}, smem, step, t);
+      else tile(std::false_type{}, smem, step, t);
     }
   } else {
     // ---- fast pass: pipelined over the steps --------------------------------------------------------------------
@@ -407,11 +492,7 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
 #pragma unroll
         for (int k = 0; k < L::NST; ++k) {
           st_src[k] += st_inc[k];
-#if BEVR_VARIANT & 64
-          st[k] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};   // timing experiment: no staging loads
-#else
           st[k] = gload16(st_src[k]);
-#endif
         }
       }
       // the next step's key record for the tile this wave builds: loaded unconditionally (a load under a branch is
@@ -421,32 +502,19 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
       const int nstep_c = min(step + 1, n_step - 1);
       const int tb = builder_of(step + 1, 1) == wave ? 1 : 0;
       const bool bld = more && builder_of(step + 1, tb) == wave;
-#if BEVR_VARIANT & 128
-      const KeyW kwn = KeyW{0, 0.3f, 999.2f, 8 * 2};   // timing experiment: no key-record load
-#else
       const KeyW kwn = load_kw(nstep_c, tb);
-#endif
       const StepBox sbb = sb_nxt[tb];
       const StepBox sbo = sb_nxt[1 - tb];
       sb_nxt[0] = kbox[2 * min(step + 2, n_step - 1)];
       sb_nxt[1] = kbox[2 * min(step + 2, n_step - 1) + 1];
 
-#if BEVR_VARIANT & 2
-      const u32x4 cw2[2] = {*reinterpret_cast<const u32x4*>(base + L::OFF_CT), *reinterpret_cast<const u32x4*>(base + L::OFF_CT + 16)};
-#endif
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        // the tile's geometry, computed once by the builder: one broadcast read instead of ~40 instructions per wave
-#if BEVR_VARIANT & 2
-        const u32x4 cw = cw2[t];
-#else
-        const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);
-#endif
-        const int live = __builtin_amdgcn_readfirstlane((int)cw[0]), fast = __builtin_amdgcn_readfirstlane((int)cw[1]);
-        if (!live || !fast) continue;   // nothing to do / the slow pass's tile (uniform)
-        tile(std::false_type{}, base, step, t, __builtin_amdgcn_readfirstlane((int)cw[2]),
-             __builtin_amdgcn_readfirstlane((int)cw[3]));
-      }
+      // the tiles' geometry, computed once by the builder: one broadcast read each instead of ~40 instructions per wave
+      const u32x4 cw0 = *reinterpret_cast<const u32x4*>(base + L::OFF_CT);
+      const u32x4 cw1 = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + 16);
+      const int ok0 = __builtin_amdgcn_readfirstlane((int)(cw0[0] & cw0[1])), ok1 = __builtin_amdgcn_readfirstlane((int)(cw1[0] & cw1[1]));
+      const int x00 = __builtin_amdgcn_readfirstlane((int)cw0[2]), a00 = __builtin_amdgcn_readfirstlane((int)cw0[3]);
+      const int x01 = __builtin_amdgcn_readfirstlane((int)cw1[2]), a01 = __builtin_amdgcn_readfirstlane((int)cw1[3]);
+      if (ok0 | ok1) tile2(std::false_type{}, base, step, ok0, ok1, x00, a00, x01, a01);
 
       if (more) {
         if (bld) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
@@ -457,20 +525,17 @@ __global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
           *reinterpret_cast<u32x4*>(nb + st_dst[k]) = st[k];
         stage_direct(nb, step + 1, tid + L::NST * nt);
       }
-#if !(BEVR_VARIANT & 32)
       __syncthreads();
-#endif
     }
     if (n_main < n_step) {   // the peeled last step: padded keys masked
       const char* base = smem + (n_main & 1) * L::BUF;
-#pragma unroll 1
-      for (int t = 0; t < 2; ++t) {
-        const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);
-        const int live = __builtin_amdgcn_readfirstlane((int)cw[0]), fast = __builtin_amdgcn_readfirstlane((int)cw[1]);
-        if (!live || !fast) continue;
-        tile(std::true_type{}, base, n_main, t, __builtin_amdgcn_readfirstlane((int)cw[2]),
-             __builtin_amdgcn_readfirstlane((int)cw[3]));
-      }
+      const u32x4 cw0 = *reinterpret_cast<const u32x4*>(base + L::OFF_CT);
+      const u32x4 cw1 = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + 16);
+      const int ok0 = __builtin_amdgcn_readfirstlane((int)(cw0[0] & cw0[1])), ok1 = __builtin_amdgcn_readfirstlane((int)(cw1[0] & cw1[1]));
+      if (ok0 | ok1)
+        tile2(std::true_type{}, base, n_main, ok0, ok1, __builtin_amdgcn_readfirstlane((int)cw0[2]),
+              __builtin_amdgcn_readfirstlane((int)cw0[3]), __builtin_amdgcn_readfirstlane((int)cw1[2]),
+              __builtin_amdgcn_readfirstlane((int)cw1[3]));
     }
   }
 

@@ -11,7 +11,8 @@ __all__ = ["default_precision", "_lib"]
 
 
 def default_precision() -> int:
-    """BEVRENDER_PRECISION=f32|bf16|f16 (default f32: exact-f32 MFMA; bf16 is the throughput mode; f16: fp16 operands)."""
+    """BEVRENDER_PRECISION=f32|bf16x3|bf16|f16 (default f32: exact-f32 MFMA; bf16x3: f32 storage, products as three
+    split-bf16 MFMAs, f32 tolerance; bf16: the throughput mode; f16: fp16 operands)."""
     v = os.environ.get("BEVRENDER_PRECISION", "f32").lower()
     if v in ("bf16", "bfloat16"):
         return _lib.PREC_BF16
@@ -19,7 +20,9 @@ def default_precision() -> int:
         return _lib.PREC_F16
     if v in ("f32", "fp32", "float32"):
         return _lib.PREC_F32
-    raise ValueError(f"BEVRENDER_PRECISION={v!r}: expected f32, bf16 or f16")
+    if v in ("bf16x3", "f32s", "split"):
+        return _lib.PREC_BF16X3
+    raise ValueError(f"BEVRENDER_PRECISION={v!r}: expected f32, bf16x3, bf16 or f16")
 
 
 def resolve_precision(p) -> int:
@@ -27,6 +30,6 @@ def resolve_precision(p) -> int:
         return default_precision()
     if isinstance(p, str):
         return {"f32": _lib.PREC_F32, "fp32": _lib.PREC_F32, "float32": _lib.PREC_F32,
-                "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16,
+                "bf16": _lib.PREC_BF16, "bfloat16": _lib.PREC_BF16, "bf16x3": _lib.PREC_BF16X3,
                 "f16": _lib.PREC_F16, "fp16": _lib.PREC_F16, "float16": _lib.PREC_F16, "half": _lib.PREC_F16}[p.lower()]
     return int(p)

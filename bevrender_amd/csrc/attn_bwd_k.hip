@@ -714,6 +714,9 @@ extern "C" int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const voi
   if (d->precision == BEVR_PREC_F16)
     return launch<BEVR_PREC_F16>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
                                  dkey_a, dkey_b, st);
+  if (d->precision == BEVR_PREC_BF16X3)
+    return launch<BEVR_PREC_BF16X3>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
+                               dkey_a, dkey_b, st);
   return launch<BEVR_PREC_F32>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
                                dkey_a, dkey_b, st);
 }

@@ -219,7 +219,14 @@ __global__ __launch_bounds__(TQ, is16(PREC) ? 4 : 2) void attn_bwd_q_kernel(
                            __builtin_bit_cast(float, w[k] & 0xffff0000u) * gscale);
       dof.v[h] = __builtin_bit_cast(bf16x8, w);
     }
-  } else if constexpr (PREC == BEVR_PREC_F32) {
+  } else if constexpr (PREC == BEVR_PREC_BF16X3) {   // both planes; gscale is a power of two: exact
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const unsigned w = __builtin_bit_cast(unsigned, dof.v[k]);
+      dof.v[k] = __builtin_bit_cast(float, pack_bf16x2(__builtin_bit_cast(float, w << 16) * gscale,
+                                                        __builtin_bit_cast(float, w & 0xffff0000u) * gscale));
+    }
+  } else if constexpr (!is16(PREC)) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) dof.v[k] *= gscale;
   }
@@ -678,5 +685,7 @@ extern "C" int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const voi
                                   st);
   if (d->precision == BEVR_PREC_F16)
     return launch<BEVR_PREC_F16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
+  if (d->precision == BEVR_PREC_BF16X3)
+    return launch<BEVR_PREC_BF16X3>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
   return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
 }

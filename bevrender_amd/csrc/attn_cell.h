@@ -39,6 +39,14 @@ constexpr int CELL_R = 4;   // table rows per chunk
 //   f32 : step t    of lane half h  <->  cell k' = 2 t + h      = (column t >> 1,         row 2 (t & 1) + h)
 template <int PREC> struct CellFrag { bf16x8 v; };                 // the 16-bit operand modes (raw bits)
 template <> struct CellFrag<BEVR_PREC_F32> { float v[8]; };
+// split mode: the same container as raw bits, v[0..3] = hi plane (8 bf16, element t <-> f32 step t), v[4..7] = lo plane
+template <> struct CellFrag<BEVR_PREC_BF16X3> : CellFrag<BEVR_PREC_F32> {};
+__device__ __forceinline__ void cell_split(CellFrag<BEVR_PREC_BF16X3>& f) {
+  const Split8 sp = split8(f.v);
+  put8(f.v, sp.hi);
+  put8(f.v + 4, sp.lo);
+}
+template <int PREC> __device__ __forceinline__ void cell_split(CellFrag<PREC>&) {}
 
 template <int PREC>
 __device__ __forceinline__ f32x16 mma_cell(const CellFrag<PREC>& a, const CellFrag<PREC>& b, f32x16 acc) {
@@ -49,12 +57,27 @@ __device__ __forceinline__ f32x16 mma_cell(const CellFrag<BEVR_PREC_F32>& a, con
   for (int t = 0; t < 8; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], b.v[t], acc, 0, 0, 0);
   return acc;
 }
+__device__ __forceinline__ f32x16 mma_cell(const CellFrag<BEVR_PREC_BF16X3>& a, const CellFrag<BEVR_PREC_BF16X3>& b, f32x16 acc) {
+  return mma_split(Split8{raw8(a.v), raw8(a.v + 4)}, Split8{raw8(b.v), raw8(b.v + 4)}, acc);
+}
 
 __device__ __forceinline__ float hat(float u) { return fmaxf(1.0f - fabsf(u), 0.f); }
 
 // Bilinear weights of this lane's key over the chunk's cells.  tcol = tx - x0 (column coordinate relative to chunk
 // column 0: integer part = first tap column, fraction = fx), trow = a - A0 likewise.  A masked key passes tcol = -8.
 template <int PREC> __device__ __forceinline__ CellFrag<PREC> cell_weights(float tcol, float trow, int h) {
+  if constexpr (!is16(PREC)) {
+    const float wy0 = hat((float)h - trow), wy1 = hat((float)(2 + h) - trow);
+    CellFrag<PREC> f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float wx = hat((float)c - tcol);
+      f.v[2 * c] = wx * wy0;
+      f.v[2 * c + 1] = wx * wy1;
+    }
+    cell_split(f);
+    return f;
+  } else {
   const float wx0 = hat((float)(2 * h) - tcol), wx1 = hat((float)(2 * h + 1) - tcol);
   float wy[4];
 #pragma unroll
@@ -67,17 +90,7 @@ template <int PREC> __device__ __forceinline__ CellFrag<PREC> cell_weights(float
   CellFrag<PREC> f;
   f.v = __builtin_bit_cast(bf16x8, w);
   return f;
-}
-template <> __device__ __forceinline__ CellFrag<BEVR_PREC_F32> cell_weights<BEVR_PREC_F32>(float tcol, float trow, int h) {
-  const float wy0 = hat((float)h - trow), wy1 = hat((float)(2 + h) - trow);
-  CellFrag<BEVR_PREC_F32> f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float wx = hat((float)c - tcol);
-    f.v[2 * c] = wx * wy0;
-    f.v[2 * c + 1] = wx * wy1;
   }
-  return f;
 }
 
 // The table side of a chunk for this lane's BEV row: chunk column 0 = table column xc0, chunk row 0 for this lane =
@@ -86,6 +99,19 @@ template <> __device__ __forceinline__ CellFrag<BEVR_PREC_F32> cell_weights<BEVR
 // taps stay inside, attn_keyprep.hip), so what a clamped read returns is irrelevant as long as it is finite.
 template <int PREC>
 __device__ __forceinline__ CellFrag<PREC> cell_table(const char* tbl, const bevr_attn_desc& d, int xc0, int yr0, int h) {
+  if constexpr (!is16(PREC)) {
+    const int ea = max(0, min(yr0 + h + d.y_off, d.Hp - 1)), eb = max(0, min(yr0 + h + 2 + d.y_off, d.Hp - 1));
+    CellFrag<PREC> f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int xc = max(0, min(xc0 + c + d.x_off, d.Wp - 1));
+      const char* col = tbl + (size_t)xc * d.Hp * 8;
+      f.v[2 * c] = *reinterpret_cast<const float*>(col + (size_t)ea * 8);
+      f.v[2 * c + 1] = *reinterpret_cast<const float*>(col + (size_t)eb * 8);
+    }
+    cell_split(f);
+    return f;
+  } else {
   const int e0 = max(0, min(yr0 + d.y_off, d.Hp - 1)), e2 = max(0, min(yr0 + d.y_off + 2, d.Hp - 1));
   u32x4 w;
 #pragma unroll
@@ -100,20 +126,7 @@ __device__ __forceinline__ CellFrag<PREC> cell_table(const char* tbl, const bevr
   CellFrag<PREC> f;
   f.v = __builtin_bit_cast(bf16x8, w);
   return f;
-}
-template <>
-__device__ __forceinline__ CellFrag<BEVR_PREC_F32> cell_table<BEVR_PREC_F32>(const char* tbl, const bevr_attn_desc& d,
-                                                                              int xc0, int yr0, int h) {
-  const int ea = max(0, min(yr0 + h + d.y_off, d.Hp - 1)), eb = max(0, min(yr0 + h + 2 + d.y_off, d.Hp - 1));
-  CellFrag<BEVR_PREC_F32> f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int xc = max(0, min(xc0 + c + d.x_off, d.Wp - 1));
-    const char* col = tbl + (size_t)xc * d.Hp * 8;
-    f.v[2 * c] = *reinterpret_cast<const float*>(col + (size_t)ea * 8);
-    f.v[2 * c + 1] = *reinterpret_cast<const float*>(col + (size_t)eb * 8);
   }
-  return f;
 }
 
 // Geometry of one 32-key tile for BEV column j (uniform over the workgroup: functions of the scalar-loaded StepBox).

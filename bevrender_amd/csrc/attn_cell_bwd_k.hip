@@ -19,18 +19,17 @@
 #include "attn_cell.h"
 #include "attn_kstage.h"
 
-#ifndef BEVR_VARIANT
-#define BEVR_VARIANT 0
-#endif
 
 namespace {
 
-constexpr int TWC = 768;             // 12 waves x 32 keys, 3 waves per SIMD: one workgroup per CU
-constexpr int KEYS_WGC = TWC / 2;    // 384 keys per workgroup
+// 16-bit modes: 12 waves x 32 keys, 3 waves per SIMD (168 registers): one workgroup per CU.  f32-layout modes: fragments
+// twice as wide -- 8 waves, 2 per SIMD (256 registers), no spills.
+template <int PREC> constexpr int twc() { return is16(PREC) ? 768 : 512; }
+template <int PREC> constexpr int keys_wgc() { return twc<PREC>() / 2; }
 
 // derivative weights of this lane's key over the chunk (see the header): cn / rn = first tap column / row relative to the
 // chunk origin (integers), wx / wy as cell_weights
-template <int PREC>
+template <int PREC, std::enable_if_t<is16(PREC), int> = 0>
 __device__ __forceinline__ void cell_dweights(float tcol, float trow, int h, CellFrag<PREC>& wyf, CellFrag<PREC>& wxf) {
   const float cn = floorf(tcol), rn = floorf(trow);
   float wx[2], dx[2], wy[4], dy[4];
@@ -56,8 +55,8 @@ __device__ __forceinline__ void cell_dweights(float tcol, float trow, int h, Cel
   wyf.v = __builtin_bit_cast(bf16x8, a);
   wxf.v = __builtin_bit_cast(bf16x8, b);
 }
-__device__ __forceinline__ void cell_dweights(float tcol, float trow, int h, CellFrag<BEVR_PREC_F32>& wyf,
-                                              CellFrag<BEVR_PREC_F32>& wxf) {
+template <int PREC, std::enable_if_t<!is16(PREC), int> = 0>
+__device__ __forceinline__ void cell_dweights(float tcol, float trow, int h, CellFrag<PREC>& wyf, CellFrag<PREC>& wxf) {
   const float cn = floorf(tcol), rn = floorf(trow);
   float wy[2], dy[2];
 #pragma unroll
@@ -75,16 +74,19 @@ __device__ __forceinline__ void cell_dweights(float tcol, float trow, int h, Cel
     wxf.v[2 * c] = dx * wy[0];
     wxf.v[2 * c + 1] = dx * wy[1];
   }
+  cell_split(wyf);
+  cell_split(wxf);
 }
 
 template <int PREC, bool SLOW>
-__global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
+__global__ __launch_bounds__(twc<PREC>(), is16(PREC) ? 3 : 2) void attn_cell_bwd_k_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ Qt, const char* __restrict__ K,
     const char* __restrict__ V, const char* __restrict__ key_ws, const char* __restrict__ table_pair,
     const char* __restrict__ dO, const char* __restrict__ dOt, const float* __restrict__ LSE,
     const float* __restrict__ delta, const float* __restrict__ grad_scale, float* __restrict__ dK,
     float* __restrict__ dV, float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
   typedef LdsK<PREC, 1> L;
+  constexpr int TWC = twc<PREC>(), KEYS_WGC = keys_wgc<PREC>();
   // fp16 mode (include/bevrender_hip.h, grad_scale[2..5]): P' = P 2^kp, dS16 = P' (dP - delta) c2
   const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
   const float ds_inv = PREC == BEVR_PREC_F16 ? grad_scale[4] : 1.f, p_inv = PREC == BEVR_PREC_F16 ? grad_scale[5] : 1.f;
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(TWC, 3) void attn_cell_bwd_k_kernel(
         } else {
 #pragma unroll
           for (int k = 0; k < 8; ++k) tf.v[k] = traw[k];
+          cell_split(tf);
         }
         s = mma_cell(tf, wf, s);
 #pragma unroll
@@ -356,6 +359,7 @@ template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K, const void* V, const void* key_ws,
            const float* table_pair, const void* dO, const void* dOt, const float* LSE, const float* delta,
            const float* gs, float* dK, float* dV, float* dka, float* dkb, hipStream_t st) {
+  constexpr int TWC = twc<PREC>(), KEYS_WGC = keys_wgc<PREC>();
   const int n_kb = (d.Np + KEYS_WGC - 1) / KEYS_WGC;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_kb;
@@ -392,6 +396,9 @@ extern "C" int bevr_attn_cell_bwd_k(const bevr_attn_desc* d, const void* Q, cons
   if (d->precision == BEVR_PREC_F16)
     return launch<BEVR_PREC_F16>(*d, Q, Qt, K, V, key_ws, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV, dkey_a,
                                  dkey_b, st);
+  if (d->precision == BEVR_PREC_BF16X3)
+    return launch<BEVR_PREC_BF16X3>(*d, Q, Qt, K, V, key_ws, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV, dkey_a,
+                               dkey_b, st);
   return launch<BEVR_PREC_F32>(*d, Q, Qt, K, V, key_ws, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV, dkey_a,
                                dkey_b, st);
 }

@@ -71,7 +71,7 @@ __device__ __forceinline__ void chunk_map_q(int g, const char* Kh, const char* V
 
 // acc1 += A1 * X, acc2 += A2 * X with X an accumulator-layout tile used as the B operand of both (bevr_common.h:
 // mma_acc_b), converted to bf16 once.
-template <int PREC>
+template <int PREC, std::enable_if_t<is16(PREC), int> = 0>
 __device__ __forceinline__ void mma_acc_b2(const Frag<PREC>& a1, const Frag<PREC>& a2, const f32x16& x, f32x16& acc1,
                                            f32x16& acc2) {
 #pragma unroll
@@ -84,14 +84,17 @@ __device__ __forceinline__ void mma_acc_b2(const Frag<PREC>& a1, const Frag<PREC
     acc2 = Half<PREC>::mfma(a2.v[s], b, acc2);
   }
 }
-__device__ __forceinline__ void mma_acc_b2(const Frag<BEVR_PREC_F32>& a1, const Frag<BEVR_PREC_F32>& a2, const f32x16& x,
-                                           f32x16& acc1, f32x16& acc2) {
+template <int PREC, std::enable_if_t<!is16(PREC), int> = 0>
+__device__ __forceinline__ void mma_acc_b2(const Frag<PREC>& a1, const Frag<PREC>& a2, const f32x16& x, f32x16& acc1,
+                                           f32x16& acc2) {
   acc1 = mma_acc_b(a1, x, acc1);
   acc2 = mma_acc_b(a2, x, acc2);
 }
 
-template <int PREC, bool SLOW>
-__global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
+// MAXT: the launch bound.  1024 threads (BEV sides up to 512) cap a wave at 128 registers; the f32-layout modes need
+// more than that (fragments twice as wide) and get a 512-thread instantiation (BEV sides up to 256) without spills.
+template <int PREC, bool SLOW, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_cell_bwd_q_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Kt,
     const char* __restrict__ V, const char* __restrict__ key_ws, const char* __restrict__ table_pair,
     const char* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
@@ -373,6 +376,20 @@ __global__ __launch_bounds__(1024) void attn_cell_bwd_q_kernel(
           const unsigned short hv = (unsigned short)(e & 1 ? wv[e >> 1] >> 16 : wv[e >> 1] & 0xffffu);
           *reinterpret_cast<unsigned short*>(wt + (8 * hi + e) * L::WT_STRIDE) = hv;
         }
+      } else if constexpr (PREC == BEVR_PREC_BF16X3) {
+        // w holds the two bf16 planes (attn_cell.h); its transpose goes into the split perm32 block format
+        // (bevr_common.h): f32 position q = 16 s + 8 h + j -> hi plane chunk 2 h + s, lo plane chunk 4 + 2 h + s
+        *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
+        *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
+        const int q = perm32(lq);
+        char* wq = bb + L::OFF_WT + t * L::WT_TILE + (2 * ((q >> 3) & 1) + (q >> 4)) * 16 + 2 * (q & 7);
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {   // cell k' = 2 t8 + hi
+          const unsigned hw = __builtin_bit_cast(unsigned, w.v[t8 >> 1]), lw = __builtin_bit_cast(unsigned, w.v[4 + (t8 >> 1)]);
+          char* row = wq + (2 * t8 + hi) * L::WT_STRIDE;
+          *reinterpret_cast<unsigned short*>(row) = (unsigned short)(t8 & 1 ? hw >> 16 : hw & 0xffffu);
+          *reinterpret_cast<unsigned short*>(row + 64) = (unsigned short)(t8 & 1 ? lw >> 16 : lw & 0xffffu);
+        }
       } else {
         *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
         *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
@@ -486,12 +503,22 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt
   const size_t lds = 2 * L::BUF + (size_t)n_wave * L::QSLOT;
   const size_t lds_slow = lds + (size_t)(d.Np / 32) * 4;
   if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
-  hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
+  if (!is16(PREC) && 64 * n_wave <= 512)
+    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
+                     (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
+                     (const char*)dO, LSE, delta, gs, dQ, dtable);
+  else
+    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false, 1024>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
                      (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
                      (const char*)dO, LSE, delta, gs, dQ, dtable);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d,
+  if (!is16(PREC) && 64 * n_wave <= 512)
+    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d,
+                     (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
+                     (const char*)table_pair, (const char*)dO, LSE, delta, gs, dQ, dtable);
+  else
+    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true, 1024>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d,
                      (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
                      (const char*)table_pair, (const char*)dO, LSE, delta, gs, dQ, dtable);
   return (int)hipGetLastError();
@@ -517,5 +544,7 @@ extern "C" int bevr_attn_cell_bwd_q(const bevr_attn_desc* d, const void* Q, cons
     return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
   if (d->precision == BEVR_PREC_F16)
     return launch<BEVR_PREC_F16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
+  if (d->precision == BEVR_PREC_BF16X3)
+    return launch<BEVR_PREC_BF16X3>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
   return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
 }

@@ -85,8 +85,10 @@ __device__ __forceinline__ void chunk_map(int g, const char* Kh, const char* Vh,
   }
 }
 
-template <int PREC, bool SLOW>
-__global__ __launch_bounds__(1024) void attn_cell_fwd_kernel(
+// MAXT: the launch bound.  1024 threads (BEV sides up to 512) cap a wave at 128 registers; the f32-layout modes need
+// more than that (fragments twice as wide) and get a 512-thread instantiation (BEV sides up to 256) without spills.
+template <int PREC, bool SLOW, int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_cell_fwd_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Vt,
     const char* __restrict__ key_ws, const char* __restrict__ table_pair, const float* __restrict__ O_in,
     const float* __restrict__ LSE_in, float* __restrict__ O, float* __restrict__ LSE) {
@@ -569,14 +571,23 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Vt
   const int grid = ((n_ph + 7) / 8) * 8 * d.S;
   const int n_wave = d.Sp / 32;
   const size_t lds = 2 * L::BUF + (size_t)n_wave * L::QSLOT;
-  hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
+  if (!is16(PREC) && 64 * n_wave <= 512)
+    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
+                     (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O_in, LSE_in, O, LSE);
+  else
+    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false, 1024>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
                      (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O_in, LSE_in, O, LSE);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   // slow pass, in place: continues from the fast pass's state; its LDS also holds the list of slow tiles
   const size_t lds_slow = lds + (size_t)(d.Np / 32) * 4;
   if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
-  hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d, (const char*)Q,
+  if (!is16(PREC) && 64 * n_wave <= 512)
+    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d, (const char*)Q,
+                     (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, (const float*)O,
+                     (const float*)LSE, O, LSE);
+  else
+    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true, 1024>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d, (const char*)Q,
                      (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, (const float*)O,
                      (const float*)LSE, O, LSE);
   return (int)hipGetLastError();
@@ -599,5 +610,7 @@ extern "C" int bevr_attn_cell_fwd(const bevr_attn_desc* d, const void* Q, const 
     return launch<BEVR_PREC_BF16>(*d, Q, K, Vt, key_ws, table_pair, O_in, LSE_in, O, LSE, st);
   if (d->precision == BEVR_PREC_F16)
     return launch<BEVR_PREC_F16>(*d, Q, K, Vt, key_ws, table_pair, O_in, LSE_in, O, LSE, st);
+  if (d->precision == BEVR_PREC_BF16X3)
+    return launch<BEVR_PREC_BF16X3>(*d, Q, K, Vt, key_ws, table_pair, O_in, LSE_in, O, LSE, st);
   return launch<BEVR_PREC_F32>(*d, Q, K, Vt, key_ws, table_pair, O_in, LSE_in, O, LSE, st);
 }

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(TF, is16(PREC) ? 4 : 2) void attn_fwd_kernel(
       float tm = s[0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
-      if constexpr (PREC == BEVR_PREC_F32) smax = fmaxf(smax, tm + m);
+      if constexpr (!is16(PREC)) smax = fmaxf(smax, tm + m);
       const bool first = (step == 0 && ks == 0);
       if (first || __any(tm > rescale_thr<PREC>())) {   // wave-uniform: rare after the first tiles
         // the two lane halves hold the same queries (different keys): agree on the maximum only when it is needed
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(TF, is16(PREC) ? 4 : 2) void attn_fwd_kernel(
       // BF16 mode: every logit of the row is <= m + RESCALE_THR (a tile above that moves m), so P <= 2^THR / l -- free,
       // where tracking the exact maximum costs a register and 7 % of the kernel at 128 VGPRs.  F32 mode (the parity
       // mode, 212 VGPRs): the exact maximum.
-      Lh[(size_t)n_ph * Mp + mq] = PREC == BEVR_PREC_F32 ? smax_row - lse : rescale_thr<PREC>() - __log2f(lt);
+      Lh[(size_t)n_ph * Mp + mq] = !is16(PREC) ? smax_row - lse : rescale_thr<PREC>() - __log2f(lt);
     }
   }
 }
@@ -452,5 +452,7 @@ extern "C" int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void*
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16) return launch_fwd<BEVR_PREC_BF16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
   if (d->precision == BEVR_PREC_F16) return launch_fwd<BEVR_PREC_F16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
+  if (d->precision == BEVR_PREC_BF16X3)
+    return launch_fwd<BEVR_PREC_BF16X3>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
   return launch_fwd<BEVR_PREC_F32>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
 }

@@ -29,7 +29,7 @@ struct KeyW {
 // Column capacity of the table regions, per precision mode and kernel (the LDS budgets are in the kernels).
 // The key-preparation kernel sizes the GROUPS of a half (below) for the smaller of the two.
 __host__ __device__ constexpr int region_cap_fwd(int prec) { return 88; }
-__host__ __device__ constexpr int region_cap_bwd_q(int prec) { return prec != BEVR_PREC_F32 ? 56 : 48; }
+__host__ __device__ constexpr int region_cap_bwd_q(int prec) { return is16(prec) ? 56 : 48; }
 __host__ __device__ constexpr int region_cap_min(int prec) {
   return region_cap_fwd(prec) < region_cap_bwd_q(prec) ? region_cap_fwd(prec) : region_cap_bwd_q(prec);
 }
@@ -135,6 +135,7 @@ template <> struct ColKeyT<BEVR_PREC_F32> {
   __device__ __forceinline__ float w10() const { return f10; }
   __device__ __forceinline__ float w11() const { return f11; }
 };
+template <> struct ColKeyT<BEVR_PREC_BF16X3> : ColKeyT<BEVR_PREC_F32> {};
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent window ("region"): a fixed-capacity box of the table, WIN_PITCH rows x NCOL columns, anchored

@@ -40,10 +40,11 @@ template <int PREC> struct Elem;
 template <> struct Elem<BEVR_PREC_F32> { typedef float type; static constexpr int bytes = 4; };
 template <> struct Elem<BEVR_PREC_BF16> { typedef __bf16 type; static constexpr int bytes = 2; };
 template <> struct Elem<BEVR_PREC_F16> { typedef _Float16 type; static constexpr int bytes = 2; };
+template <> struct Elem<BEVR_PREC_BF16X3> { typedef float type; static constexpr int bytes = 4; };   // f32 storage
 
 // the two 16-bit operand modes share every layout and all storage (kept as raw bits in bf16x8 / uint32 registers); what
 // differs is the arithmetic on the bits
-__host__ __device__ constexpr bool is16(int prec) { return prec != BEVR_PREC_F32; }
+__host__ __device__ constexpr bool is16(int prec) { return prec == BEVR_PREC_BF16 || prec == BEVR_PREC_F16; }
 template <int PREC> struct Half;
 template <> struct Half<BEVR_PREC_BF16> {
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
@@ -107,6 +108,46 @@ template <> struct Frag<BEVR_PREC_F32> {
   }
 };
 
+// BEVR_PREC_BF16X3: the f32-tolerance mode on the bf16 matrix cores.  Every matrix operand is SPLIT x = hi + lo
+// (hi = bf16(x), lo = bf16(x - hi), both round-to-nearest) and a product is three MFMAs,
+//   a b ~= a_lo b_hi + a_hi b_lo + a_hi b_hi,   dropped: a_lo b_lo <= 2^-16 |a b|   (f32 accumulation as always):
+// three 32x32x16 bf16 MFMAs (3 x 32 clk) replace eight 32x32x2 f32 MFMAs (8 x 64 clk) per 16 contraction indices.
+// The packed operands in HBM and LDS keep the f32 modes' sizes, strides and addressing -- a 32-element row or 32-block is
+// 128 bytes, a lane reads the same 64 of them -- but hold the two bf16 planes instead of floats (formats below: the
+// caller / bevr_pack_kv split ONCE per element; the kernels split only what they produce themselves, P and dS).
+// Everything per-pair (bias taps, table window, softmax) is the f32 modes' code.  The fragment types keep the f32
+// containers as raw bits, so that every copy (LDS slots, staging) is shared with BEVR_PREC_F32:
+//   Frag<X3>.v[0..3] = hi plane of k-step 0 (8 bf16), v[4..7] = hi of k-step 1, v[8..11] / v[12..15] = the lo planes.
+//   row layout, per 16-element half [e0..e15] (64 B):  hi(e0..e7) | hi(e8..e15) | lo(e0..e7) | lo(e8..e15)
+//   transposed (perm32) layout, per 32-block (128 B), chunk c = 16 B: with y[q] the block in the f32 mode's order,
+//     chunk 2 h + s = hi(y[16 s + 8 h .. + 7]),  chunk 4 + 2 h + s = lo(same)        (h = lane half, s = k-step)
+template <> struct Frag<BEVR_PREC_BF16X3> : Frag<BEVR_PREC_F32> {};   // same loads (load_perm binds to the base)
+struct Split8 { bf16x8 hi, lo; };
+__device__ __forceinline__ Split8 split8(const float* x) {
+  u32x4 h, l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    h[k] = pack_bf16x2(x[2 * k], x[2 * k + 1]);
+    const float f0 = __builtin_bit_cast(float, h[k] << 16), f1 = __builtin_bit_cast(float, h[k] & 0xffff0000u);
+    l[k] = pack_bf16x2(x[2 * k] - f0, x[2 * k + 1] - f1);
+  }
+  return Split8{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, l)};
+}
+// the planes of 4 raw dwords each out of a fragment container
+__device__ __forceinline__ bf16x8 raw8(const float* v) {
+  return __builtin_bit_cast(bf16x8, f32x4{v[0], v[1], v[2], v[3]});
+}
+__device__ __forceinline__ void put8(float* v, bf16x8 b) {
+  const f32x4 t = __builtin_bit_cast(f32x4, b);
+  v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+}
+__device__ __forceinline__ f32x16 mma_split(const Split8& a, const Split8& b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);   // small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+  return acc;
+}
+
 // acc += A(rows x 32) * B(32 x cols) for one 32x32 tile, both operands as Frag (contraction over the
 // fragment's 32 elements in matching order).
 __device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_BF16>& a, const Frag<BEVR_PREC_BF16>& b, f32x16 acc) {
@@ -122,6 +163,13 @@ __device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_F16>& a, const F
 __device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_F32>& a, const Frag<BEVR_PREC_F32>& b, f32x16 acc) {
 #pragma unroll
   for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b.v[s], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ f32x16 mma_frag(const Frag<BEVR_PREC_BF16X3>& a, const Frag<BEVR_PREC_BF16X3>& b, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    acc = mma_split(Split8{raw8(a.v + 4 * s), raw8(a.v + 8 + 4 * s)}, Split8{raw8(b.v + 4 * s), raw8(b.v + 8 + 4 * s)}, acc);
   return acc;
 }
 
@@ -155,6 +203,18 @@ __device__ __forceinline__ f32x16 mma_acc_b(const Frag<BEVR_PREC_F32>& a, const 
   // NOT that set -- the f32 A operand for an accumulator contraction is loaded with load_perm below.
 #pragma unroll
   for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], x[t], acc, 0, 0, 0);
+  return acc;
+}
+
+// the accumulator-layout operand is split here; element j of k-step s <-> x[8 s + j], as in the 16-bit modes
+__device__ __forceinline__ f32x16 mma_acc_b(const Frag<BEVR_PREC_BF16X3>& a, const f32x16& x, f32x16 acc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    float xs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xs[k] = x[8 * s + k];
+    acc = mma_split(Split8{raw8(a.v + 4 * s), raw8(a.v + 8 + 4 * s)}, split8(xs), acc);
+  }
   return acc;
 }
 
@@ -205,8 +265,7 @@ static inline int bevr_check_desc(const bevr_attn_desc* d) {
   bevr_attn_desc t = *d;
   if (bevr_attn_table_dims(&t) != 0) return BEVR_E_SHAPE;
   if (t.Hp != d->Hp || t.Wp != d->Wp || t.y_off != d->y_off || t.x_off != d->x_off) return BEVR_E_SHAPE;
-  if (d->precision != BEVR_PREC_F32 && d->precision != BEVR_PREC_BF16 && d->precision != BEVR_PREC_F16)
-    return BEVR_E_PRECISION;
+  if (d->precision < BEVR_PREC_F32 || d->precision > BEVR_PREC_BF16X3) return BEVR_E_PRECISION;
   // 32-bit byte offsets into one head's pair table
   if ((long long)d->Hp * d->Wp * 8 >= (1LL << 31)) return BEVR_E_SHAPE;
   return BEVR_OK;

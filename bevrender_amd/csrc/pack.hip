@@ -27,7 +27,15 @@ template <> __device__ __forceinline__ half_bits to_elem<half_bits>(float x) {
 }
 
 // One workgroup = 64 consecutive keys of one problem, all heads, K and V.
-template <typename E>
+// SPLIT (BEVR_PREC_BF16X3; E = float): the same strides and addresses, but every 128 bytes hold the hi and lo bf16 planes
+// of their 32 values in the order the split-mode fragments read them (bevr_common.h, Frag<BEVR_PREC_BF16X3>).
+__device__ __forceinline__ void split_bf16(float x, unsigned short& h, unsigned short& l) {
+  const unsigned hb = pack_bf16x2(x, 0.f) & 0xffffu;
+  h = (unsigned short)hb;
+  l = (unsigned short)(pack_bf16x2(x - __builtin_bit_cast(float, hb << 16), 0.f) & 0xffffu);
+}
+
+template <typename E, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ k, const float* __restrict__ v,
                                                       long long ld, long long pstride, int N, int Np, int heads, int c,
                                                       E* __restrict__ Kr, E* __restrict__ Vr, E* __restrict__ Kt,
@@ -59,6 +67,45 @@ __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
+  if constexpr (SPLIT) {
+    // row layout: per (row, 16-element half): hi(e0..7) | hi(e8..15) | lo(e0..7) | lo(e8..15); one thread per 8 elements
+    for (int i = tid; i < 2 * heads * PK * 4; i += 256) {
+      const int g8 = i & 3, key = (i >> 2) % PK, hk = i / (4 * PK);
+      const int kind = hk / heads, head = hk - kind * heads;
+      const E* srcp = tile + (hk * PK + key) * 32 + g8 * 8;
+      unsigned short hb[8], lb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split_bf16(srcp[e], hb[e], lb[e]);
+      char* dst = reinterpret_cast<char*>((kind ? Vr : Kr) + (((size_t)b * all_heads + head0 + head) * Np + n0 + key) * 32) +
+                  (g8 >> 1) * 64 + (g8 & 1) * 16;
+      u32x4 w;
+      __builtin_memcpy(&w, hb, 16);
+      *reinterpret_cast<u32x4*>(dst) = w;
+      __builtin_memcpy(&w, lb, 16);
+      *reinterpret_cast<u32x4*>(dst + 32) = w;
+    }
+    // transposed layout, per 32-key block: chunk 2 h + s = hi(y[16 s + 8 h ..+7]), chunk 4 + 2 h + s = lo(same),
+    // y[q] = X[perm32(q)]; one thread per (row, block, h, s)
+    for (int i = tid; i < 2 * heads * 32 * (PK / 32) * 4; i += 256) {
+      const int hs = i & 3, blk = (i >> 2) % (PK / 32), ch = (i / (4 * (PK / 32))) % 32, hk = i / (4 * (PK / 32) * 32);
+      const int kind = hk / heads, head = hk - kind * heads;
+      E* dbase = kind ? Vt : Kt;
+      if (!dbase) continue;
+      const int h = hs >> 1, sst = hs & 1;
+      unsigned short hb[8], lb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        split_bf16(tile[(hk * PK + blk * 32 + perm32(16 * sst + 8 * h + e)) * 32 + ch], hb[e], lb[e]);
+      char* dst = reinterpret_cast<char*>(dbase + (((size_t)b * all_heads + head0 + head) * 32 + ch) * Np + n0 + blk * 32) +
+                  (2 * h + sst) * 16;
+      u32x4 w;
+      __builtin_memcpy(&w, hb, 16);
+      *reinterpret_cast<u32x4*>(dst) = w;
+      __builtin_memcpy(&w, lb, 16);
+      *reinterpret_cast<u32x4*>(dst + 64) = w;
+    }
+    return;
+  }
   constexpr int EPC = 16 / sizeof(E);      // elements per 16-byte chunk
   constexpr int CPR = 32 / EPC;            // chunks per 32-element row
   // row layout: (head, key) rows of 32 elements, 64 keys contiguous per head
@@ -113,10 +160,10 @@ extern "C" int bevr_pack_kv(const float* k, const float* v, long long ld, long l
   if (n_prob <= 0 || N <= 0 || Np < N || Np % PK || heads <= 0 || c <= 0 || c > 32 || ld < (long long)heads * c ||
       pstride < N)
     return BEVR_E_SHAPE;
-  if (precision != BEVR_PREC_BF16 && precision != BEVR_PREC_F32 && precision != BEVR_PREC_F16) return BEVR_E_PRECISION;
+  if (precision < BEVR_PREC_F32 || precision > BEVR_PREC_BF16X3) return BEVR_E_PRECISION;
   if (!bevr_aligned16(Kr) || !bevr_aligned16(Vr) || (Kt && !bevr_aligned16(Kt)) || (Vt && !bevr_aligned16(Vt)))
     return BEVR_E_ALIGN;
-  const size_t eb = precision == BEVR_PREC_F32 ? 4 : 2;
+  const size_t eb = is16(precision) ? 2 : 4;
   const int hg = (int)(32768 / (2 * PK * 32 * eb));
   const dim3 grid(Np / PK, n_prob, (heads + hg - 1) / hg);
   const size_t lds = (size_t)2 * (heads < hg ? heads : hg) * PK * 32 * eb;
@@ -127,6 +174,9 @@ extern "C" int bevr_pack_kv(const float* k, const float* v, long long ld, long l
   else if (precision == BEVR_PREC_BF16)
     hipLaunchKernelGGL(pack_kv_kernel<unsigned short>, grid, dim3(256), lds, st, k, v, ld, pstride, N, Np, heads, c,
                        (unsigned short*)Kr, (unsigned short*)Vr, (unsigned short*)Kt, (unsigned short*)Vt);
+  else if (precision == BEVR_PREC_BF16X3)
+    hipLaunchKernelGGL((pack_kv_kernel<float, true>), grid, dim3(256), lds, st, k, v, ld, pstride, N, Np, heads, c,
+                       (float*)Kr, (float*)Vr, (float*)Kt, (float*)Vt);
   else
     hipLaunchKernelGGL(pack_kv_kernel<float>, grid, dim3(256), lds, st, k, v, ld, pstride, N, Np, heads, c, (float*)Kr,
                        (float*)Vr, (float*)Kt, (float*)Vt);

@@ -265,6 +265,34 @@ def _perm_t(x: torch.Tensor) -> torch.Tensor:
     return x.index_select(-2, perm_index(L, x.device)).transpose(-1, -2).contiguous()
 
 
+def _split_rows(x: torch.Tensor) -> torch.Tensor:
+    """(.., 32) float rows -> the split-bf16 row format of BEVR_PREC_BF16X3 (csrc/bevr_common.h), same shape and dtype
+    as a raw container: per 16-element half  hi(e0..7) | hi(e8..15) | lo(e0..7) | lo(e8..15),  hi = bf16(x), lo = bf16(x - hi)."""
+    sh = x.shape[:-1]
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    out = torch.stack((hi.reshape(*sh, 2, 16), lo.reshape(*sh, 2, 16)), dim=-2)        # (.., half, plane, 16)
+    return out.reshape(*sh, 64).contiguous().view(torch.float32)
+
+
+def _unsplit_rows(xs: torch.Tensor) -> torch.Tensor:
+    """hi + lo of a split row container (.., 32) -> float (.., 32)."""
+    sh = xs.shape[:-1]
+    b = xs.contiguous().view(torch.bfloat16).reshape(*sh, 2, 2, 16).float()
+    return (b[..., 0, :] + b[..., 1, :]).reshape(*sh, 32)
+
+
+def _split_perm_t(x: torch.Tensor) -> torch.Tensor:
+    """(.., L, 32) float rows -> (.., 32, L) transposed split format: per 32-block, with y the block in perm32 order,
+    16-byte chunk 2 h + s = hi(y[16 s + 8 h .. + 7]), chunk 4 + 2 h + s = lo(same)."""
+    y = _perm_t(x)
+    sh, L = y.shape[:-1], y.shape[-1]
+    hi = y.to(torch.bfloat16)
+    lo = (y - hi.float()).to(torch.bfloat16)
+    out = torch.stack((hi.reshape(*sh, L // 32, 2, 2, 8), lo.reshape(*sh, L // 32, 2, 2, 8)), dim=-4)  # (.., blk, plane, s, h, 8)
+    return out.transpose(-3, -2).reshape(*sh, 2 * L).contiguous().view(torch.float32)
+
+
 def _attn_flops(geom, n_matmul, n_keys=None):
     """algorithmic MFMA flops of one attention launch: 2 flop/MAC x head_dim 32 x query-key pairs."""
     n = geom.N if n_keys is None else n_keys
@@ -306,7 +334,8 @@ class _AttnCore(torch.autograd.Function):
         _require_gpu(Qp, kv, key_a, key_b, Tt)
         L = _lib.lib()
         ed = _edtype(geom.precision)
-        Qe = Qp.to(ed).contiguous()
+        x3 = geom.precision == _lib.PREC_BF16X3
+        Qe = _split_rows(Qp.float()) if x3 else Qp.to(ed).contiguous()
         kv = kv.float().contiguous()
         N, C2 = kv.shape[1], kv.shape[-1]
         c = C2 // 2 // geom.heads
@@ -353,6 +382,8 @@ class _AttnCore(torch.autograd.Function):
                                             _stream()), "bevr_attn_fwd")
             saved += [Ke, Ve, Kt, ka, kb, key_ws]
         ctx.geom = geom
+        # split mode: the packed V is not readable as numbers; the norm bound of the backward's scales from the rows
+        ctx.vmax = kv[..., C2 // 2:].reshape(kv.shape[0], N, geom.heads, c).norm(dim=-1).max() if x3 and need_bwd else None
         ctx.segs = segs
         ctx.kv_shape = kv.shape
         ctx.save_for_backward(Qe, pair, O, LSE, *saved)
@@ -372,18 +403,20 @@ class _AttnCore(torch.autograd.Function):
             # brought to ~2^10 with a power of two (exact) here and the gradients are scaled back below.  No host sync.
             sdo = torch.exp2(torch.floor(10.0 - torch.log2(dO.abs().max().clamp_min(1e-30))))
             dO = dO * sdo
-        dOe = dO.to(ed).contiguous()
+        x3 = geom.precision == _lib.PREC_BF16X3
+        dOe = _split_rows(dO.float()) if x3 else dO.to(ed).contiguous()
         # delta = rowsum(dO o O) from the SAME (rounded) dO the kernels contract with V for dP: dS = P (dP - delta) then
         # cancels as it must where P -> 1 (with the f32 dO here and the bf16 one there, |dS| kept a floor of
         # 2^-9 |dO||V| -- pure noise in dQ, dK, d(pos), d(table) of a row dominated by one key)
-        delta = (dOe.float() * O).sum(-1).contiguous()
+        dOr = dO.float() if x3 else dOe.float()
+        delta = (dOr * O).sum(-1).contiguous()
         dev = dO.device
         # zeros: bwd_q walks the grid in 31-row tiles and never visits the padded rows S..Sp-1 of a column; the cell
         # kernels add their segment's share
         dQ = torch.zeros(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
         dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
-        Qt = _perm_t(Qe)
-        dOt = _perm_t(dOe)
+        Qt = _split_perm_t(_unsplit_rows(Qe)) if x3 else _perm_t(Qe)
+        dOt = _split_perm_t(dOr) if x3 else _perm_t(dOe)
         N, C2 = ctx.kv_shape[1], ctx.kv_shape[-1]
         dkv = torch.empty(ctx.kv_shape, device=dev, dtype=torch.float32)
         # Scales of the backward kernels (include/bevrender_hip.h, grad_scale[8]); powers of two, on the device, no sync.
@@ -394,8 +427,9 @@ class _AttnCore(torch.autograd.Function):
         #             dO and delta as it loads them -- exact -- and ln2 / s when it stores);
         #   fp16 only: [2] kp with Pmax 2^kp <= 2^14 (softmax weights as fp16 operands), [3] c2 with
         #             Pmax bound 2^kp c2 <= 2^14 (logit gradients as fp16 operands), [4], [5] the inverses; s = 2^16 2^kp c2.
-        vmax = torch.stack([saved[6 * i + 1].float().norm(dim=-1).max() for i in range(len(ctx.segs))]).max()
-        bound = (dOe.float().norm(dim=-1).max() * vmax + delta.abs().max()).clamp_min(1e-30)
+        vmax = ctx.vmax if x3 else \
+            torch.stack([saved[6 * i + 1].float().norm(dim=-1).max() for i in range(len(ctx.segs))]).max()
+        bound = (dOr.norm(dim=-1).max() * vmax + delta.abs().max()).clamp_min(1e-30)
         pmax_log2 = (LSE[1].max() + 0.05).clamp(-60.0, 0.0)
         zero, one = torch.zeros((), device=dev), torch.ones((), device=dev)
         if f16:

@@ -53,7 +53,11 @@ enum {
 /* BEVR_PREC_F16: fp16 operands (v_mfma_f32_32x32x16_f16), f32 accumulate -- BASELINE config 5.  fp16 has 5 exponent bits:
  * the kernels keep softmax weights and logit gradients inside its normal range with power-of-two scales (forward: the
  * softmax reference sits 10 binades below the running maximum; backward: grad_scale[2..5]). */
-enum { BEVR_PREC_F32 = 0, BEVR_PREC_BF16 = 1, BEVR_PREC_F16 = 2 };
+/* BEVR_PREC_BF16X3: the fp32-tolerance mode that is not bound by the f32 matrix rate.  Storage, layouts and every
+ *   per-pair f32 computation are those of BEVR_PREC_F32 (E = float in the packed operands, f32 table window); each matrix
+ *   product runs as three bf16 MFMAs on operands split hi + lo in registers (x = bf16(x) + bf16(x - bf16(x)); the
+ *   lo x lo term, <= 2^-16 of the product, is dropped).  Results agree with BEVR_PREC_F32 to ~1e-5 relative. */
+enum { BEVR_PREC_F32 = 0, BEVR_PREC_BF16 = 1, BEVR_PREC_F16 = 2, BEVR_PREC_BF16X3 = 3 };
 
 int bevr_abi_version(void);
 /* Human-readable text for a BEVR_E_* code (static storage). */

@@ -194,8 +194,9 @@ LIMITS = {
     # fp16 operands (BASELINE config 5): 11-bit significands against bf16's 8 -- between the two tables above
     _lib.PREC_F16: dict(out=2.5e-3, query=5e-3, k=5e-3, v=4e-3, pos=8e-3, table=5e-3),
 }
-TAG = {_lib.PREC_F32: "f32", _lib.PREC_BF16: "bf16", _lib.PREC_F16: "f16"}
-ALL_PREC = [_lib.PREC_F32, _lib.PREC_BF16, _lib.PREC_F16]
+LIMITS[_lib.PREC_BF16X3] = LIMITS[_lib.PREC_F32]   # split-bf16 products: the f32 limits
+TAG = {_lib.PREC_F32: "f32", _lib.PREC_BF16: "bf16", _lib.PREC_F16: "f16", _lib.PREC_BF16X3: "bf16x3"}
+ALL_PREC = [_lib.PREC_F32, _lib.PREC_BF16X3, _lib.PREC_BF16, _lib.PREC_F16]
 
 
 @pytest.mark.parametrize("prec", ALL_PREC)

@@ -19,7 +19,8 @@ DEV = "cuda"
 # F16 = fp16 operands (11-bit significand against bf16's 8): its limits sit between the two.
 TOL = {_lib.PREC_F32: dict(rtol=2e-4, atol=2e-5), _lib.PREC_BF16: dict(rtol=3e-2, atol=1.5e-2),
        _lib.PREC_F16: dict(rtol=6e-3, atol=3e-3)}
-GRAD_LIM = {_lib.PREC_F32: 5e-4, _lib.PREC_BF16: 3e-2, _lib.PREC_F16: 6e-3}
+TOL[_lib.PREC_BF16X3] = TOL[_lib.PREC_F32]   # the split-bf16 mode is held to the f32 limits everywhere
+GRAD_LIM = {_lib.PREC_F32: 5e-4, _lib.PREC_BF16X3: 5e-4, _lib.PREC_BF16: 3e-2, _lib.PREC_F16: 6e-3}
 
 
 def rel_err(got, want):
@@ -64,7 +65,7 @@ CORE_CFGS = [
 ]
 
 
-@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16, _lib.PREC_F16])
+@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16X3, _lib.PREC_BF16, _lib.PREC_F16])
 @pytest.mark.parametrize("cfg", CORE_CFGS)
 def test_attention_core_forward_backward(cfg, prec):
     B, V, C, h, g, S, D, N = cfg
@@ -436,6 +437,30 @@ def test_depthwise_conv_matches_torch(shape, nhwc):
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(wg.grad.cpu().numpy(), wr.grad.numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 300, 2, 32), (2, 129, 2, 8), (1, 65, 5, 24)])
+def test_pack_kv_split_format(shape):
+    """BEVR_PREC_BF16X3: bevr_pack_kv writes the hi / lo bf16 planes in the fragment order (csrc/bevr_common.h) -- bit
+    for bit what ops._split_rows / ops._split_perm_t make of the f32 packing, and hi + lo returns the values to 2^-16."""
+    import ctypes as C
+    Bp, N, h, c = shape
+    Cc = h * c
+    Np = 64 * ((N + 63) // 64)
+    kv = torch.randn(Bp, N, 2 * Cc, generator=torch.Generator().manual_seed(N)).to(DEV)
+    Kr = torch.full((Bp, h, Np, 32), 7.0, device=DEV)
+    Vr, Kt = torch.full_like(Kr, 7.0), torch.full((Bp, h, 32, Np), 7.0, device=DEV)
+    Vt = torch.full_like(Kt, 7.0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert _lib.lib().bevr_pack_kv(p(kv), C.c_void_p(kv.data_ptr() + 4 * Cc), 2 * Cc, N, Bp, N, Np, h, c, _lib.PREC_BF16X3,
+                                   p(Kr), p(Vr), p(Kt), p(Vt), st) == 0
+    Kw, Vw = ops.pack_keys(kv[..., :Cc], h).contiguous(), ops.pack_keys(kv[..., Cc:], h).contiguous()
+    as_bits = lambda t: t.view(torch.int32)
+    assert torch.equal(as_bits(Kr), as_bits(ops._split_rows(Kw))) and torch.equal(as_bits(Vr), as_bits(ops._split_rows(Vw)))
+    assert torch.equal(as_bits(Kt), as_bits(ops._split_perm_t(Kw))) and torch.equal(as_bits(Vt), as_bits(ops._split_perm_t(Vw)))
+    assert (ops._unsplit_rows(Kr) - Kw).abs().max().item() <= 2.0 ** -16 * Kw.abs().max().item()
 
 
 @pytest.mark.gpu

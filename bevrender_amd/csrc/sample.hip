@@ -187,6 +187,172 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_kernel(const float* __r
   }
 }
 
+// Backward with an LDS patch (the benchmark path: C / 4 divides the workgroup size).
+//
+// The keys arrive in k-d order of their reference pixels (ops.split_key_order; the pinned keys cell-sorted behind
+// them), so a run of consecutive keys touches a compact patch of the feature map -- at the benchmark rig 512 keys x 4
+// taps fall on ~150 pixels.  A workgroup takes chunks of PCH_KEYS consecutive keys of one image: it finds the bounding
+// box of the chunk's taps, accumulates every tap inside a window of up to PCH_BYTES of it in LDS (ds_add_f32), and
+// flushes ONE global atomic per touched (pixel, channel): ~14x fewer global atomics than a scatter per key.  Taps
+// outside the window (a chunk that straddles the image) are scattered directly; taps on the hot corner are summed in
+// registers over all chunks of the workgroup as in sample_bwd_kernel<true>.
+constexpr int PCH_KEYS = 512, PCH_BYTES = 48 * 1024, PCH_WMAX = 32;
+
+__global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const float* __restrict__ feat,
+                                                                      const float* __restrict__ pos,
+                                                                      const float* __restrict__ dout,
+                                                                      float* __restrict__ dfeat, float* __restrict__ dpos,
+                                                                      int nb, int Hi, int Wi, int C, int N, int pow2_group) {
+  __shared__ __attribute__((aligned(16))) float patch[PCH_BYTES / 4];   // the window; at the end the hot corner's partials
+  __shared__ int s_box[SB_THREADS / 64][4];
+  const int c4n = C >> 2, tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int slots = SB_THREADS / c4n, slot = tid / c4n, c4 = tid % c4n;
+  const int pix_cap = PCH_BYTES / (C * 4);
+  const size_t img = (size_t)b * Hi * Wi * C;
+  const float* fb = feat + img + c4 * 4;
+  float* gimg = dfeat + img;
+  f32x4 hot[HOT_R * HOT_C];
+#pragma unroll
+  for (int p = 0; p < HOT_R * HOT_C; ++p) hot[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n_chunk = (N + PCH_KEYS - 1) / PCH_KEYS;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+
+  for (int chunk = blockIdx.x; chunk < n_chunk; chunk += gridDim.x) {
+    const int k0 = chunk * PCH_KEYS, nk = min(PCH_KEYS, N - k0);
+    // ---- bounding box of the chunk's taps (inside the image, outside the hot corner) ----
+    int xlo = 1 << 30, xhi = -1, ylo = 1 << 30, yhi = -1;
+    for (int kk = tid; kk < nk; kk += SB_THREADS) {
+      const f32x2 p = *reinterpret_cast<const f32x2*>(pos + ((size_t)b * N + k0 + kk) * 2);
+      const Taps t = make_taps(p[0], p[1], Hi, Wi);
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int x = t.x0 + dx, y = t.y0 + dy;
+          const bool in = x >= 0 && x < Wi && y >= 0 && y < Hi && !(y < HOT_R && x < HOT_C);
+          if (in) { xlo = min(xlo, x); xhi = max(xhi, x); ylo = min(ylo, y); yhi = max(yhi, y); }
+        }
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+      xlo = min(xlo, __shfl_xor(xlo, sh)); xhi = max(xhi, __shfl_xor(xhi, sh));
+      ylo = min(ylo, __shfl_xor(ylo, sh)); yhi = max(yhi, __shfl_xor(yhi, sh));
+    }
+    if ((tid & 63) == 0) { s_box[tid >> 6][0] = xlo; s_box[tid >> 6][1] = xhi; s_box[tid >> 6][2] = ylo; s_box[tid >> 6][3] = yhi; }
+    __syncthreads();   // also: the previous chunk's flush is complete
+#pragma unroll
+    for (int w = 0; w < SB_THREADS / 64; ++w) {
+      xlo = min(xlo, s_box[w][0]); xhi = max(xhi, s_box[w][1]); ylo = min(ylo, s_box[w][2]); yhi = max(yhi, s_box[w][3]);
+    }
+    const int pw = xhi >= xlo ? min(xhi - xlo + 1, PCH_WMAX) : 0;
+    const int ph = pw > 0 ? min(yhi - ylo + 1, pix_cap / pw) : 0;
+    const int n_el = ph * pw * C;
+    for (int u = tid * 4; u < n_el; u += SB_THREADS * 4) *reinterpret_cast<f32x4*>(patch + u) = z;
+    __syncthreads();
+
+    // ---- the chunk's keys, `slots` at a time (whole waves stay converged for the shuffles) ----
+    const int nk_pad = (nk + slots - 1) / slots * slots;
+    for (int kk = slot; kk < nk_pad; kk += slots) {
+      const bool live = kk < nk;
+      const size_t kn = (size_t)b * N + k0 + (live ? kk : nk - 1);
+      const f32x2 p = *reinterpret_cast<const f32x2*>(pos + kn * 2);
+      const Taps t = make_taps(p[0], p[1], Hi, Wi);
+      const f32x4 g = live ? *reinterpret_cast<const f32x4*>(dout + kn * C + c4 * 4) : z;
+      const bool bv[4] = {t.vy0 && t.vx0, t.vy0 && t.vx1, t.vy1 && t.vx0, t.vy1 && t.vx1};
+      const float wv[4] = {(1.f - t.fx) * (1.f - t.fy), t.fx * (1.f - t.fy), (1.f - t.fx) * t.fy, t.fx * t.fy};
+      f32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const size_t o = ((size_t)(t.y0 + (q >> 1)) * Wi + t.x0 + (q & 1)) * C;
+        v[q] = bv[q] ? *reinterpret_cast<const f32x4*>(fb + o) : z;
+      }
+      if (live) {
+        // hot corner: weight of hot pixel (r, c) = wy[r] * wx[c] (no data-dependent register index)
+#pragma unroll
+        for (int r = 0; r < HOT_R; ++r) {
+          const float wy = (t.y0 == r ? 1.f - t.fy : 0.f) + (t.y0 + 1 == r ? t.fy : 0.f);
+#pragma unroll
+          for (int c = 0; c < HOT_C; ++c) {
+            const float wx = (t.x0 == c ? 1.f - t.fx : 0.f) + (t.x0 + 1 == c ? t.fx : 0.f);
+            hot[r * HOT_C + c] += g * (wy * wx);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int x = t.x0 + (q & 1), y = t.y0 + (q >> 1);
+          if (!bv[q] || (y < HOT_R && x < HOT_C)) continue;
+          const int px = x - xlo, py = y - ylo;
+          if (px >= 0 && px < pw && py >= 0 && py < ph) {
+            // element (pixel, c4, k) at pixel * C + ((k * c4n + c4 + 16 * pixel) mod C): the key slots of a wave land on
+            // different bank groups when their pixels differ
+            const int pix = py * pw + px;
+            float* pp = patch + pix * C;
+            const int rot = c4 + 16 * pix;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(pp + ((k * c4n + rot) % C), g[k] * wv[q]);
+          } else {
+            float* gp = gimg + ((size_t)y * Wi + x) * C + c4 * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(gp + k, g[k] * wv[q]);
+          }
+        }
+      }
+      float gx = 0.f, gy = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gx += g[k] * ((v[1][k] - v[0][k]) * (1.f - t.fy) + (v[3][k] - v[2][k]) * t.fy);
+        gy += g[k] * ((v[2][k] - v[0][k]) * (1.f - t.fx) + (v[3][k] - v[1][k]) * t.fx);
+      }
+      gx *= 0.5f * (float)(Wi - 1);
+      gy *= 0.5f * (float)(Hi - 1);
+      if (pow2_group) {
+        for (int sh = c4n >> 1; sh > 0; sh >>= 1) {
+          gx += __shfl_xor(gx, sh);
+          gy += __shfl_xor(gy, sh);
+        }
+        if (live && c4 == 0) *reinterpret_cast<f32x2*>(dpos + kn * 2) = f32x2{gy, gx};
+      } else if (live) {
+        atomicAdd(dpos + kn * 2, gy);
+        atomicAdd(dpos + kn * 2 + 1, gx);
+      }
+    }
+    __syncthreads();
+    // ---- flush the window: one atomic per touched (pixel, channel), 256-B rows ----
+    for (int u = tid; u < ph * pw * c4n; u += SB_THREADS) {
+      const int pix = u / c4n, cc = u % c4n;
+      const float* pp = patch + pix * C;
+      const int rot = cc + 16 * pix;
+      float a[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = pp[(k * c4n + rot) % C];
+      if (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f || a[3] != 0.f) {
+        float* gp = gimg + ((size_t)(ylo + pix / pw) * Wi + xlo + pix % pw) * C + cc * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(gp + k, a[k]);
+      }
+    }
+  }
+  // ---- hot corner: reduce the workgroup's partials (the threads that share a channel quad) and flush ----
+  __syncthreads();
+  constexpr int NP = HOT_R * HOT_C;
+  static_assert(NP * SB_THREADS * 16 <= PCH_BYTES, "hot partials reuse the patch");
+#pragma unroll
+  for (int p = 0; p < NP; ++p) *reinterpret_cast<f32x4*>(patch + ((size_t)p * SB_THREADS + tid) * 4) = hot[p];
+  __syncthreads();
+  for (int u = tid; u < NP * c4n; u += SB_THREADS) {
+    const int p = u / c4n, cc = u % c4n;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int sl = 0; sl < slots; ++sl) a += *reinterpret_cast<const f32x4*>(patch + ((size_t)p * SB_THREADS + sl * c4n + cc) * 4);
+    const int r = p / HOT_C, c = p % HOT_C;
+    if (r < Hi && c < Wi && (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f || a[3] != 0.f)) {
+      float* gp = gimg + ((size_t)r * Wi + c) * C + cc * 4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(gp + k, a[k]);
+    }
+  }
+}
+
 int grid_for(long long total) {
   long long g = (total + 255) / 256;
   if (g > 256 * 16) g = 256 * 16;  // grid-stride the rest
@@ -220,19 +386,24 @@ extern "C" int bevr_sample_bwd(const float* feat, const float* pos, const float*
     hipError_t e = hipMemsetAsync(dpos, 0, (size_t)nb * N * 2 * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
-  // one image per workgroup row; enough workgroups per image to fill the chip, few enough that the per-workgroup
-  // reduction of the hot corner is amortised over >= 64 keys per thread slot
-  const long long per_img = (long long)N * c4n;
-  long long gx = (per_img + SB_THREADS - 1) / SB_THREADS;
-  const long long want = (256LL * 16 + nb - 1) / nb;
-  if (gx > want) gx = want;
-  if (gx < 1) gx = 1;
-  const bool hot = (SB_THREADS % c4n) == 0;
-  if (hot)
-    hipLaunchKernelGGL((sample_bwd_kernel<true>), dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream, feat,
+  const bool patch_ok = (SB_THREADS % c4n) == 0 && C * 4 * 32 <= PCH_BYTES;
+  if (patch_ok) {
+    // chunks of consecutive keys; a workgroup takes several (the hot corner's partials are reduced once per workgroup)
+    const int n_chunk = (N + PCH_KEYS - 1) / PCH_KEYS;
+    long long gx = n_chunk;
+    const long long want = (256LL * 12 + nb - 1) / nb;
+    if (gx > want) gx = want;
+    hipLaunchKernelGGL(sample_bwd_patch_kernel, dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream, feat,
                        pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, pow2);
-  else
+  } else {
+    // one image per workgroup row, grid-stride over its keys, every tap scattered
+    const long long per_img = (long long)N * c4n;
+    long long gx = (per_img + SB_THREADS - 1) / SB_THREADS;
+    const long long want = (256LL * 16 + nb - 1) / nb;
+    if (gx > want) gx = want;
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL((sample_bwd_kernel<false>), dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream, feat,
                        pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, pow2);
+  }
   return (int)hipGetLastError();
 }

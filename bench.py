@@ -287,7 +287,8 @@ def main():
 
     gen = torch.Generator(device=dev).manual_seed(15213 + rank)
     # backbone features as the backbone hands them over: channels-last (the sampler's layout, no copy)
-    feats = [torch.randn(B * V, C, Hi, Wi, device=dev, dtype=torch.bfloat16, generator=gen).float()
+    # bf16 in HBM (north_star: bf16 input); the sampler reads them as they are (csrc/sample.hip, bevr_sample_*_bf16)
+    feats = [torch.randn(B * V, C, Hi, Wi, device=dev, dtype=torch.bfloat16, generator=gen)
              .contiguous(memory_format=torch.channels_last) for _ in range(2)]
     map_emb = torch.nn.functional.normalize(torch.randn(B, C * S * S, device=dev, generator=gen), dim=1)
 

@@ -455,7 +455,11 @@ __global__ __launch_bounds__(MAXT) void attn_cell_bwd_q_kernel(
       }
 
       if (more) {
+#if defined(BEVR_VARIANT) && BEVR_VARIANT == 2   // timing probe only (stale weights): what the builder wave costs the step
+        if (bld && step < 2) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
+#else
         if (bld) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
+#endif
         if (n_wave == 1) build_w(buf ^ 1, step + 1, 1 - tb, load_kw(step + 1, 1 - tb), sbo);
         char* nb = smem + (buf ^ 1) * L::BUF;
 #pragma unroll

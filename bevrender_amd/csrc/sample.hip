@@ -11,6 +11,15 @@
 
 namespace {
 
+// feature element: float, or bf16 (the backbone's output dtype in the bf16 configurations: 8-byte tap reads instead of 16)
+struct bf16_bits { unsigned short u; };
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_bits* p) {
+  const uint2 w = *reinterpret_cast<const uint2*>(p);
+  return f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+               __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+}
+
 struct Taps {
   int x0, y0;
   float fx, fy;
@@ -36,7 +45,8 @@ __device__ __forceinline__ Taps make_taps(float py, float px, int Hi, int Wi) {
   return t;
 }
 
-__global__ __launch_bounds__(256) void sample_fwd_kernel(const float* __restrict__ feat,
+template <typename T>
+__global__ __launch_bounds__(256) void sample_fwd_kernel(const T* __restrict__ feat,
                                                          const float* __restrict__ pos, float* __restrict__ out,
                                                          int nb, int Hi, int Wi, int C, int N) {
   const int c4n = C >> 2;
@@ -48,12 +58,12 @@ __global__ __launch_bounds__(256) void sample_fwd_kernel(const float* __restrict
     const int b = (int)(kn / N);
     const f32x2 p = *reinterpret_cast<const f32x2*>(pos + kn * 2);
     const Taps t = make_taps(p[0], p[1], Hi, Wi);
-    const float* fb = feat + (size_t)b * Hi * Wi * C + c4 * 4;
+    const T* fb = feat + (size_t)b * Hi * Wi * C + c4 * 4;
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 v00 = (t.vy0 && t.vx0) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)t.y0 * Wi + t.x0) * C) : z;
-    f32x4 v01 = (t.vy0 && t.vx1) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)t.y0 * Wi + t.x0 + 1) * C) : z;
-    f32x4 v10 = (t.vy1 && t.vx0) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)(t.y0 + 1) * Wi + t.x0) * C) : z;
-    f32x4 v11 = (t.vy1 && t.vx1) ? *reinterpret_cast<const f32x4*>(fb + ((size_t)(t.y0 + 1) * Wi + t.x0 + 1) * C) : z;
+    f32x4 v00 = (t.vy0 && t.vx0) ? load4(fb + ((size_t)t.y0 * Wi + t.x0) * C) : z;
+    f32x4 v01 = (t.vy0 && t.vx1) ? load4(fb + ((size_t)t.y0 * Wi + t.x0 + 1) * C) : z;
+    f32x4 v10 = (t.vy1 && t.vx0) ? load4(fb + ((size_t)(t.y0 + 1) * Wi + t.x0) * C) : z;
+    f32x4 v11 = (t.vy1 && t.vx1) ? load4(fb + ((size_t)(t.y0 + 1) * Wi + t.x0 + 1) * C) : z;
     const float w00 = (1.f - t.fx) * (1.f - t.fy), w01 = t.fx * (1.f - t.fy);
     const float w10 = (1.f - t.fx) * t.fy, w11 = t.fx * t.fy;
     f32x4 r = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
@@ -75,8 +85,8 @@ __global__ __launch_bounds__(256) void sample_fwd_kernel(const float* __restrict
 // workgroup.  A workgroup stays inside one image so that the sums stay separable.
 constexpr int HOT_R = 4, HOT_C = 2, SB_THREADS = 256;
 
-template <bool HOT>
-__global__ __launch_bounds__(SB_THREADS) void sample_bwd_kernel(const float* __restrict__ feat,
+template <bool HOT, typename T>
+__global__ __launch_bounds__(SB_THREADS) void sample_bwd_kernel(const T* __restrict__ feat,
                                                                 const float* __restrict__ pos,
                                                                 const float* __restrict__ dout,
                                                                 float* __restrict__ dfeat, float* __restrict__ dpos,
@@ -100,16 +110,16 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_kernel(const float* __r
     const f32x2 p = *reinterpret_cast<const f32x2*>(pos + kn * 2);
     const Taps t = make_taps(p[0], p[1], Hi, Wi);
     const size_t fo = img + c4 * 4;
-    const float* fb = feat + fo;
+    const T* fb = feat + fo;
     float* gb = dfeat + fo;
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 g = live ? *reinterpret_cast<const f32x4*>(dout + kn * C + c4 * 4) : z;
     const bool b00 = t.vy0 && t.vx0, b01 = t.vy0 && t.vx1, b10 = t.vy1 && t.vx0, b11 = t.vy1 && t.vx1;
     const size_t o00 = ((size_t)t.y0 * Wi + t.x0) * C, o01 = o00 + C, o10 = o00 + (size_t)Wi * C, o11 = o10 + C;
-    f32x4 v00 = b00 ? *reinterpret_cast<const f32x4*>(fb + o00) : z;
-    f32x4 v01 = b01 ? *reinterpret_cast<const f32x4*>(fb + o01) : z;
-    f32x4 v10 = b10 ? *reinterpret_cast<const f32x4*>(fb + o10) : z;
-    f32x4 v11 = b11 ? *reinterpret_cast<const f32x4*>(fb + o11) : z;
+    f32x4 v00 = b00 ? load4(fb + o00) : z;
+    f32x4 v01 = b01 ? load4(fb + o01) : z;
+    f32x4 v10 = b10 ? load4(fb + o10) : z;
+    f32x4 v11 = b11 ? load4(fb + o11) : z;
     const float w00 = (1.f - t.fx) * (1.f - t.fy), w01 = t.fx * (1.f - t.fy);
     const float w10 = (1.f - t.fx) * t.fy, w11 = t.fx * t.fy;
     // which taps fall on the hot corner (those are summed in registers, the others scattered)
@@ -198,7 +208,8 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_kernel(const float* __r
 // registers over all chunks of the workgroup as in sample_bwd_kernel<true>.
 constexpr int PCH_KEYS = 512, PCH_BYTES = 48 * 1024, PCH_WMAX = 32;
 
-__global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const float* __restrict__ feat,
+template <typename T>
+__global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const T* __restrict__ feat,
                                                                       const float* __restrict__ pos,
                                                                       const float* __restrict__ dout,
                                                                       float* __restrict__ dfeat, float* __restrict__ dpos,
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const floa
   const int slots = SB_THREADS / c4n, slot = tid / c4n, c4 = tid % c4n;
   const int pix_cap = PCH_BYTES / (C * 4);
   const size_t img = (size_t)b * Hi * Wi * C;
-  const float* fb = feat + img + c4 * 4;
+  const T* fb = feat + img + c4 * 4;
   float* gimg = dfeat + img;
   f32x4 hot[HOT_R * HOT_C];
 #pragma unroll
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const floa
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const size_t o = ((size_t)(t.y0 + (q >> 1)) * Wi + t.x0 + (q & 1)) * C;
-        v[q] = bv[q] ? *reinterpret_cast<const f32x4*>(fb + o) : z;
+        v[q] = bv[q] ? load4(fb + o) : z;
       }
       if (live) {
         // hot corner: weight of hot pixel (r, c) = wy[r] * wx[c] (no data-dependent register index)
@@ -360,21 +371,20 @@ int grid_for(long long total) {
   return (int)g;
 }
 
-}  // namespace
-
-extern "C" int bevr_sample_fwd(const float* feat, const float* pos, float* out, int nb, int Hi, int Wi, int C,
-                               int N, void* stream) {
+template <typename T>
+int sample_fwd(const T* feat, const float* pos, float* out, int nb, int Hi, int Wi, int C, int N, void* stream) {
   if (!feat || !pos || !out) return BEVR_E_NULL;
   if (nb <= 0 || Hi < 2 || Wi < 2 || N <= 0 || C <= 0 || (C & 3) || C > 1024) return BEVR_E_SHAPE;
   if (!bevr_aligned16(feat) || !bevr_aligned16(out) || (reinterpret_cast<uintptr_t>(pos) & 7)) return BEVR_E_ALIGN;
   long long total = (long long)nb * N * (C >> 2);
-  hipLaunchKernelGGL(sample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, feat, pos, out,
+  hipLaunchKernelGGL(sample_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, feat, pos, out,
                      nb, Hi, Wi, C, N);
   return (int)hipGetLastError();
 }
 
-extern "C" int bevr_sample_bwd(const float* feat, const float* pos, const float* dout, float* dfeat, float* dpos,
-                               int nb, int Hi, int Wi, int C, int N, void* stream) {
+template <typename T>
+int sample_bwd(const T* feat, const float* pos, const float* dout, float* dfeat, float* dpos, int nb, int Hi, int Wi,
+               int C, int N, void* stream) {
   if (!feat || !pos || !dout || !dfeat || !dpos) return BEVR_E_NULL;
   if (nb <= 0 || Hi < 2 || Wi < 2 || N <= 0 || C <= 0 || (C & 3) || C > 1024) return BEVR_E_SHAPE;
   if (!bevr_aligned16(feat) || !bevr_aligned16(dout) || !bevr_aligned16(dfeat) ||
@@ -393,8 +403,8 @@ extern "C" int bevr_sample_bwd(const float* feat, const float* pos, const float*
     long long gx = n_chunk;
     const long long want = (256LL * 12 + nb - 1) / nb;
     if (gx > want) gx = want;
-    hipLaunchKernelGGL(sample_bwd_patch_kernel, dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream, feat,
-                       pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, pow2);
+    hipLaunchKernelGGL(sample_bwd_patch_kernel<T>, dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream,
+                       feat, pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, pow2);
   } else {
     // one image per workgroup row, grid-stride over its keys, every tap scattered
     const long long per_img = (long long)N * c4n;
@@ -402,8 +412,28 @@ extern "C" int bevr_sample_bwd(const float* feat, const float* pos, const float*
     const long long want = (256LL * 16 + nb - 1) / nb;
     if (gx > want) gx = want;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((sample_bwd_kernel<false>), dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream, feat,
-                       pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, pow2);
+    hipLaunchKernelGGL((sample_bwd_kernel<false, T>), dim3((unsigned)gx, nb), dim3(SB_THREADS), 0, (hipStream_t)stream,
+                       feat, pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, pow2);
   }
   return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int bevr_sample_fwd(const float* feat, const float* pos, float* out, int nb, int Hi, int Wi, int C,
+                               int N, void* stream) {
+  return sample_fwd(feat, pos, out, nb, Hi, Wi, C, N, stream);
+}
+extern "C" int bevr_sample_bwd(const float* feat, const float* pos, const float* dout, float* dfeat, float* dpos,
+                               int nb, int Hi, int Wi, int C, int N, void* stream) {
+  return sample_bwd(feat, pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, stream);
+}
+// the same on a bf16 feature map (raw bits); outputs and gradients stay float
+extern "C" int bevr_sample_fwd_bf16(const void* feat, const float* pos, float* out, int nb, int Hi, int Wi, int C,
+                                    int N, void* stream) {
+  return sample_fwd(static_cast<const bf16_bits*>(feat), pos, out, nb, Hi, Wi, C, N, stream);
+}
+extern "C" int bevr_sample_bwd_bf16(const void* feat, const float* pos, const float* dout, float* dfeat, float* dpos,
+                                    int nb, int Hi, int Wi, int C, int N, void* stream) {
+  return sample_bwd(static_cast<const bf16_bits*>(feat), pos, dout, dfeat, dpos, nb, Hi, Wi, C, N, stream);
 }

@@ -526,7 +526,9 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
 
 
 class _Sample(torch.autograd.Function):
-    """grid_sample(bilinear, align_corners=True, zeros) on a channels-last map: (nb,Hi,Wi,C),(nb,N,2)->(nb,N,C)."""
+    """grid_sample(bilinear, align_corners=True, zeros) on a channels-last map: (nb,Hi,Wi,C),(nb,N,2)->(nb,N,C).
+    The map is float or bfloat16 (read as it is: the bf16 configurations keep the backbone features bf16 in HBM); the
+    samples and every gradient are float."""
 
     @staticmethod
     def forward(ctx, feat, pos):
@@ -537,9 +539,12 @@ class _Sample(torch.autograd.Function):
         out = torch.empty(nb, N, Cc, device=feat.device, dtype=torch.float32)
         # algorithmic (compulsory) HBM bytes: the feature map once, a position and an output row per key.  The 4 taps
         # of a key are NOT 4 HBM reads: neighbouring keys share them through L2 (SURVEY 8d counts the map once too)
-        _lib.check(KERNEL_TIMER.run("bevr_sample_fwd", 0.0, _lib.lib().bevr_sample_fwd, _ptr(feat), _ptr(pos),
+        bf = feat.dtype == torch.bfloat16
+        fn = _lib.lib().bevr_sample_fwd_bf16 if bf else _lib.lib().bevr_sample_fwd
+        _lib.check(KERNEL_TIMER.run("bevr_sample_fwd", 0.0, fn, _ptr(feat), _ptr(pos),
                                     _ptr(out), nb, Hi, Wi, Cc, N, _stream(),
-                                    nbytes=4.0 * nb * (Hi * Wi * Cc + N * Cc + 2 * N)), "bevr_sample_fwd")
+                                    nbytes=4.0 * nb * (Hi * Wi * Cc * (0.5 if bf else 1.0) + N * Cc + 2 * N)),
+                   "bevr_sample_fwd")
         ctx.save_for_backward(feat, pos)
         return out
 
@@ -549,15 +554,19 @@ class _Sample(torch.autograd.Function):
         nb, Hi, Wi, Cc = feat.shape
         N = pos.shape[1]
         dout = dout.contiguous()
-        dfeat = torch.zeros_like(feat)
+        bf = feat.dtype == torch.bfloat16
+        dfeat = torch.zeros(feat.shape, device=feat.device, dtype=torch.float32)
         dpos = torch.empty_like(pos)
         # algorithmic (compulsory) HBM bytes: dout row, position and position gradient per key; the feature map read
         # once (position gradient) and its gradient written once.  What the scatter really costs is the atomic traffic
         # (4 taps x N x C floats leave L2 as memory-side atomics): bench.py reports that as `traffic` from the PMC counters
-        _lib.check(KERNEL_TIMER.run("bevr_sample_bwd", 0.0, _lib.lib().bevr_sample_bwd, _ptr(feat), _ptr(pos),
+        fn = _lib.lib().bevr_sample_bwd_bf16 if bf else _lib.lib().bevr_sample_bwd
+        _lib.check(KERNEL_TIMER.run("bevr_sample_bwd", 0.0, fn, _ptr(feat), _ptr(pos),
                                     _ptr(dout), _ptr(dfeat), _ptr(dpos), nb, Hi, Wi, Cc, N, _stream(),
-                                    nbytes=4.0 * nb * (N * Cc + 2 * Hi * Wi * Cc + 4 * N)), "bevr_sample_bwd")
-        return dfeat, dpos
+                                    nbytes=4.0 * nb * (N * Cc + (1.5 if bf else 2.0) * Hi * Wi * Cc + 4 * N)),
+                   "bevr_sample_bwd")
+        # autograd wants the input's dtype; the cast is skipped when nobody reads the map's gradient
+        return (dfeat.to(feat.dtype) if bf and ctx.needs_input_grad[0] else dfeat if not bf else None), dpos
 
 
 def sample_features(feat_nchw: torch.Tensor, pos: torch.Tensor, groups: int) -> torch.Tensor:
@@ -566,7 +575,8 @@ def sample_features(feat_nchw: torch.Tensor, pos: torch.Tensor, groups: int) -> 
     B, Cc, Hi, Wi = feat_nchw.shape
     g = groups
     N = pos.shape[1]
-    f = feat_nchw.float().reshape(B, g, Cc // g, Hi, Wi).permute(0, 1, 3, 4, 2).reshape(B * g, Hi, Wi, Cc // g)
+    f = feat_nchw if feat_nchw.dtype == torch.bfloat16 else feat_nchw.float()
+    f = f.reshape(B, g, Cc // g, Hi, Wi).permute(0, 1, 3, 4, 2).reshape(B * g, Hi, Wi, Cc // g)
     xs = _Sample.apply(f.contiguous(), pos.float())
     return xs.reshape(B, g, N, Cc // g).permute(0, 2, 1, 3).reshape(B, N, Cc)
 

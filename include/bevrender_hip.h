@@ -53,10 +53,18 @@ enum {
 /* BEVR_PREC_F16: fp16 operands (v_mfma_f32_32x32x16_f16), f32 accumulate -- BASELINE config 5.  fp16 has 5 exponent bits:
  * the kernels keep softmax weights and logit gradients inside its normal range with power-of-two scales (forward: the
  * softmax reference sits 10 binades below the running maximum; backward: grad_scale[2..5]). */
-/* BEVR_PREC_BF16X3: the fp32-tolerance mode that is not bound by the f32 matrix rate.  Storage, layouts and every
- *   per-pair f32 computation are those of BEVR_PREC_F32 (E = float in the packed operands, f32 table window); each matrix
- *   product runs as three bf16 MFMAs on operands split hi + lo in registers (x = bf16(x) + bf16(x - bf16(x)); the
- *   lo x lo term, <= 2^-16 of the product, is dropped).  Results agree with BEVR_PREC_F32 to ~1e-5 relative. */
+/* BEVR_PREC_BF16X3: the fp32-tolerance mode that is not bound by the f32 matrix rate.  Every matrix operand is split
+ *   x = hi + lo, hi = bf16(x), lo = bf16(x - hi) (round to nearest), and a product runs as three bf16 MFMAs
+ *   (lo*hi + hi*lo + hi*hi; the lo*lo term, <= 2^-16 of the product, is dropped); everything per pair -- bias taps, f32
+ *   table window, softmax -- is BEVR_PREC_F32's arithmetic.  Results agree with BEVR_PREC_F32 to ~1e-5 relative.
+ *   Packed operands (Q, K, V, dO and their transposes) keep BEVR_PREC_F32's shapes, strides and byte sizes (E = float
+ *   as a container) but hold the two bf16 planes:
+ *     row layout, per 16-element half [e0..e15] of a 32-element row (64 bytes):
+ *         hi(e0..e7) | hi(e8..e15) | lo(e0..e7) | lo(e8..e15)
+ *     transposed (bits 2 <-> 3 swapped) layout, per block of 32 (128 bytes = 8 chunks of 16 bytes), y[q] = the block in
+ *     the f32 mode's order:   chunk 2 h + s = hi(y[16 s + 8 h .. + 7]),   chunk 4 + 2 h + s = lo(same),   h, s in {0, 1}
+ *   bevr_pack_kv writes K, V in this format; bevrender_amd/ops.py (_split_rows, _split_perm_t) is the definition the
+ *   tests compare it with and what packs Q and dO. */
 enum { BEVR_PREC_F32 = 0, BEVR_PREC_BF16 = 1, BEVR_PREC_F16 = 2, BEVR_PREC_BF16X3 = 3 };
 
 int bevr_abi_version(void);
@@ -198,6 +206,12 @@ int bevr_sample_fwd(const float* feat, const float* pos, float* out,
                     int nb, int Hi, int Wi, int C, int N, void* stream);
 int bevr_sample_bwd(const float* feat, const float* pos, const float* dout, float* dfeat, float* dpos,
                     int nb, int Hi, int Wi, int C, int N, void* stream);
+/* The same on a bf16 feature map (the backbone's output dtype in the bf16 configurations; `feat` = raw bf16 bits, same
+ * shape): half the tap bytes, features stay bf16 in HBM.  out, dout, dfeat (the master gradient), dpos stay float. */
+int bevr_sample_fwd_bf16(const void* feat, const float* pos, float* out,
+                         int nb, int Hi, int Wi, int C, int N, void* stream);
+int bevr_sample_bwd_bf16(const void* feat, const float* pos, const float* dout, float* dfeat, float* dpos,
+                         int nb, int Hi, int Wi, int C, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BEV pillar grid -> camera pixels (model/bev_cmr_proj.py:61-113).

@@ -598,7 +598,7 @@ def test_sca_module_bev200_six_views_rows(prec):
     cot_full[:, :, rows.to(DEV)] = cot.to(DEV)
     out.backward(cot_full.reshape(B, C, S, S))
     torch.cuda.synchronize()
-    f32 = int(prec)
+    f32 = 0 if int(prec) == _lib.PREC_BF16X3 else int(prec)   # the split-bf16 mode is held to the f32 limits
     e = rel_err(out.detach().reshape(B, C, S * S)[:, :, rows.to(DEV)].cpu(), want.detach())
     print(f"\n[sca module S=200 V=6 prec={prec}] out rel err {e:.3e}")
     assert e < {0: 3e-4, 1: 2e-2, 2: 3e-3}[f32]
@@ -634,7 +634,7 @@ def test_tsa_module_bev200_rows(prec):
     cot_full[:, :, rows.to(DEV)] = cot.to(DEV)
     out.backward(cot_full.reshape(B, C, S, S))
     torch.cuda.synchronize()
-    f32 = int(prec)
+    f32 = 0 if int(prec) == _lib.PREC_BF16X3 else int(prec)   # the split-bf16 mode is held to the f32 limits
     e = rel_err(out.detach().reshape(B, C, S * S)[:, :, rows.to(DEV)].cpu(), want.detach())
     print(f"\n[tsa module S=200 prec={prec}] out rel err {e:.3e}")
     assert e < {0: 3e-4, 1: 2e-2, 2: 3e-3}[f32]

@@ -539,3 +539,33 @@ def test_sample_features_takes_channels_last_features_without_a_copy():
     f = cl.reshape(B, 1, Cc, Hi, Wi).permute(0, 1, 3, 4, 2).reshape(B, Hi, Wi, Cc)
     assert f.is_contiguous() and f.data_ptr() == cl.data_ptr()
     assert torch.equal(ops.sample_features(cl, pos, 1), ops.sample_features(feat, pos, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 16, 6, 10, 50), (3, 64, 64, 176, 3000), (2, 24, 9, 7, 300)])
+def test_sample_features_reads_bf16_features_as_they_are(shape):
+    """bf16 backbone features (the bf16 configurations) are sampled without a float copy of the map: a bf16 value is an
+    exact float, so the samples and the position gradient equal those of the float map bit for bit, and the map's
+    gradient is the float one rounded to bf16.  Most keys pinned to the corner, as the projector leaves them."""
+    B, Cc, Hi, Wi, N = shape
+    g = torch.Generator().manual_seed(N)
+    feat = torch.randn(B, Cc, Hi, Wi, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    pos = (torch.rand(B, N, 2, generator=g) * 2.4 - 1.2)
+    pos[:, : N // 2] = -1.0 + 0.01 * torch.randn(B, N // 2, 2, generator=g)
+    pos = pos.to(DEV)
+    cot = torch.randn(B, N, Cc, generator=g).to(DEV)
+    res = []
+    for f in (feat, feat.float()):
+        f = f.detach().requires_grad_(True)
+        p = pos.clone().requires_grad_(True)
+        out = ops.sample_features(f, p, 1)
+        out.backward(cot)
+        res.append((out.detach(), p.grad, f.grad))
+    (ob, pb, fb), (of, pf, ff) = res
+    assert ob.dtype == torch.float32 and fb.dtype == torch.bfloat16
+    assert torch.equal(ob, of)
+    # C / 4 a power of two: the position gradient is reduced in a fixed order; otherwise with float atomics
+    c4 = Cc // 4
+    assert torch.equal(pb, pf) if c4 & (c4 - 1) == 0 else torch.allclose(pb, pf, rtol=1e-4, atol=1e-4 * pf.abs().max().item())
+    # float atomics in a different order on the two runs: compare at the rounding of the bf16 result
+    assert (fb.float() - ff).abs().max().item() <= 2.0 ** -7 * ff.abs().max().item()

@@ -356,6 +356,11 @@ def main():
                     "all_attention": {k: {"avg_ms": round(v["ms"] / v["n"], 3),
                                           "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 5)}
                                       for k, v in sorted(attn.items())}}
+            # every attention launch of the timed region together: algorithmic flops / summed kernel time
+            tot_f, tot_ms = sum(v["flops"] for v in attn.values()), sum(v["ms"] for v in attn.values())
+            roof["all_attention_aggregate"] = {"achieved": round(tot_f / (tot_ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                                               "frac": round(tot_f / (tot_ms * 1e-3) / 1e12 / peak, 5),
+                                               "ms_per_step": round(tot_ms / args.steps, 2)}
         # What actually paces the attention kernels is per-pair work on the LDS pipe (bias taps, per-key constants, the
         # table-gradient atomics), not the matrix cores.  Secondary, clearly separate from
         # `roofline`: the pair rate against the rate at which one CU's LDS pipe could issue each kernel's LDS

@@ -77,19 +77,28 @@ class SCADeformableAttention(nn.Module):
         y = F.layer_norm(y, norm.norm.normalized_shape, norm.norm.weight, norm.norm.bias, norm.norm.eps)
         return F.linear(act(y), pw.weight.flatten(1), pw.bias)
 
-    def key_positions(self, query, reference_points):
+    def key_positions(self, query, reference_points, key_order=None):
         """(B, V, g, N, 2) key positions (y, x): offset head of each view, even BEV rows -> y-offset of key
-        row h, odd rows -> x-offset, key column w*D + d (reference :219-277)."""
+        row h, odd rows -> x-offset, key column w*D + d (reference :219-277), in the static key order `key_order`
+        (V, N) if given."""
         B, C, S, _ = query.shape
         g, D, V = self.n_groups, self.bev_depth_dim, self.n_views
         Hk, Wk = S // 2, S * D
         q_nhwc = query.permute(0, 2, 3, 1)            # the LayerNormProxy output underneath: contiguous, no copy
+        offs = [self._offset_head(getattr(self, f"conv_offset_m{v}"), q_nhwc, g) for v in range(V)]   # (B*g, S, S, D) each
+        fac = self.offset_range_factor if self.scale_offset_range else 1.0
+        rng_y, rng_x = fac / (Hk - 1.0), fac / (Wk - 1.0)
+        if query.is_cuda and (B == 1 or reference_points.stride(0) == 0):
+            # one HIP pass over all views: row split, tanh * range, + reference, gathered into the static key order
+            # (the references are the projector's, the same for every sample: SpatialCrossAttn broadcasts them as a view)
+            ref = reference_points[0, :, :, :, (1, 0)].reshape(V, Hk * Wk, 2)
+            return ops.key_positions(torch.stack(offs, 0), ref, key_order, B, g, sca_SD=(S, D),
+                                     use_tanh=bool(self.scale_offset_range), sy=rng_y, sx=rng_x)
         ref = reference_points[..., (1, 0)]                                  # (B, V, Hk, Wk, 2) -> (y, x)
         outs = []
         for v in range(V):
-            off = self._offset_head(getattr(self, f"conv_offset_m{v}"), q_nhwc, g)   # (B*g, S, S, D) channels-last
             # "(b g) d (h n) w -> (b g) n h (w d)", n = 2
-            off = off.reshape(B * g, Hk, 2, S, D).permute(0, 2, 1, 3, 4).reshape(B * g, 2, Hk, Wk)
+            off = offs[v].reshape(B * g, Hk, 2, S, D).permute(0, 2, 1, 3, 4).reshape(B * g, 2, Hk, Wk)
             if self.scale_offset_range:
                 rng = off.new_tensor([1.0 / (Hk - 1.0), 1.0 / (Wk - 1.0)]).reshape(1, 2, 1, 1)
                 off = off.tanh() * rng * self.offset_range_factor
@@ -97,7 +106,11 @@ class SCADeformableAttention(nn.Module):
             if not self.scale_offset_range:
                 pos = pos.clamp(-1.0, 1.0)
             outs.append(pos.reshape(B, g, Hk * Wk, 2))
-        return torch.stack(outs, 1)
+        pos = torch.stack(outs, 1)
+        if key_order is not None:
+            N = Hk * Wk
+            pos = pos.gather(3, key_order[None, :, None, :, None].expand(B, V, g, N, 2))
+        return pos
 
     def forward(self, x, query, reference_points, wandb_log_dict, return_wandb_log=True, key_order=None,
                 cell_split=None):
@@ -112,10 +125,8 @@ class SCADeformableAttention(nn.Module):
         if V != self.n_views:
             raise ValueError(f"expected {self.n_views} views, got {V}")
         g = self.n_groups
-        pos = self.key_positions(query, reference_points.to(query.dtype))       # (B, V, g, N, 2)
+        pos = self.key_positions(query, reference_points.to(query.dtype), key_order)   # (B, V, g, N, 2), key order
         N = pos.shape[3]
-        if key_order is not None:
-            pos = pos.gather(3, key_order[None, :, None, :, None].expand(B, V, g, N, 2))
         pos = pos.reshape(B * V * g, N, 2)
         if cell_split is not None and cell_split < N and g == 1:
             # groups > 1: a key is one row of K built from all groups' samples, so the groups cannot be ordered

@@ -81,6 +81,14 @@ class TSADeformableAttention(nn.Module):
             y = co[2](co[1](z))                                           # LayerNormProxy output: NHWC underneath
             off = F.linear(y.permute(0, 2, 3, 1), co[3].weight.flatten(1)).permute(0, 3, 1, 2)   # 1x1 conv as a GEMM
         Hk, Wk = off.shape[-2:]
+        if off.is_cuda and Hk > 1 and Wk > 1:
+            # tanh * range, + regular grid, gathered into the static key order: one HIP pass (ops.key_positions)
+            fac = self.offset_range_factor if self.scale_offset_range else 1.0
+            grid = normalized_grid(Hk, Wk, torch.float32, off.device).reshape(1, Hk * Wk, 2)
+            pos = ops.key_positions(off.permute(0, 2, 3, 1).reshape(1, B * g, Hk * Wk, 2), grid,
+                                    self._key_order(Hk, Wk, off.device)[None], B, g, sca_SD=None,
+                                    use_tanh=bool(self.scale_offset_range), sy=fac / (Hk - 1.0), sx=fac / (Wk - 1.0))
+            return pos.reshape(B * g, Hk * Wk, 2)
         if self.scale_offset_range:
             rng = off.new_tensor([1.0 / (Hk - 1.0), 1.0 / (Wk - 1.0)]).reshape(1, 2, 1, 1)
             off = off.tanh() * rng * self.offset_range_factor

@@ -713,6 +713,43 @@ def offset_head(x: torch.Tensor, w0, b0, gamma: torch.Tensor, beta: torch.Tensor
     return _OffsetHead.apply(x, w0, b0, gamma, beta, W3, groups, eps)
 
 
+class _KeyPositions(torch.autograd.Function):
+    """csrc/keypos.hip: offset-head outputs -> key positions in the attention's key order (one launch), and the adjoint."""
+
+    @staticmethod
+    def forward(ctx, off, ref, order, B, G, sca_SD, use_tanh, sy, sx):
+        _require_gpu(off, ref, order)
+        off, ref = off.float().contiguous(), ref.float().contiguous()
+        V, P = off.shape[0], off.shape[1]
+        N = ref.shape[1]
+        S, D = sca_SD if sca_SD else (0, 0)
+        order = None if order is None else order.to(torch.int32).contiguous()
+        pos = torch.empty(B, V, G, N, 2, device=off.device, dtype=torch.float32)
+        ctx.args = (V, P, G, N, 1 if sca_SD else 0, S, D, 1 if use_tanh else 0, float(sy), float(sx))
+        _lib.check(_lib.lib().bevr_key_positions_fwd(_ptr(off), _ptr(ref), _ptr(order), _ptr(pos), *ctx.args, _stream()),
+                   "bevr_key_positions_fwd")
+        ctx.save_for_backward(off, ref, order)
+        return pos
+
+    @staticmethod
+    def backward(ctx, dpos):
+        off, ref, order = ctx.saved_tensors
+        doff = torch.empty_like(off)
+        _lib.check(_lib.lib().bevr_key_positions_bwd(_ptr(off), _ptr(ref), _ptr(order), _ptr(dpos.float().contiguous()),
+                                                      _ptr(doff), *ctx.args, _stream()), "bevr_key_positions_bwd")
+        return doff, None, None, None, None, None, None, None, None
+
+
+def key_positions(off: torch.Tensor, ref: torch.Tensor, order: Optional[torch.Tensor], batch: int, groups: int,
+                  sca_SD=None, use_tanh: bool = True, sy: float = 1.0, sx: float = 1.0) -> torch.Tensor:
+    """off (V, B*g, ...) offset-head outputs of V views -- SCA (sca_SD = (S, D)): channels-last (S, S, D) blocks whose
+    even / odd BEV rows are the y / x offsets of key row h, key column w D + d; TSA (sca_SD None): (N, 2) blocks --,
+    ref (V, N, 2) reference points in (y, x), order (V, N) the static key order or None.  Returns (B, V, g, N, 2):
+    tanh(off) * (sy, sx) + ref (use_tanh) or clamp(off + ref, -1, 1), gathered into the key order.
+    Replaces model/SCA_deform_attn.py:248-277 and model/TSA_deform_attn.py:170-196."""
+    return _KeyPositions.apply(off, ref, order, batch, groups, sca_SD, use_tanh, sy, sx)
+
+
 # --------------------------------------------------------------------------------------------------
 # ego-motion warp of the history BEV (csrc/warp.hip)
 # --------------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@
  *   bevr_pack_kv/unpack_dkv model/SCA_deform_attn.py:312-321 (projection outputs -> per-head operand layouts)
  *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
  *   bevr_offset_head_fwd/bwd  model/SCA_deform_attn.py:56-77, model/TSA_deform_attn.py:54-68 (offset heads, fused)
+ *   bevr_key_positions_fwd/bwd  model/SCA_deform_attn.py:248-277, model/TSA_deform_attn.py:170-196 (row split, tanh range, + ref, key order)
  *   bevr_affine_warp_fwd/bwd  model/encoder.py:413-466 (project_history_bev_feat: torchvision F.affine, twice)
  *   bevr_corr_fwd/bwd       train.py:554 (2 - 2 cam map^T) and the pairwise distance inside
  *                           loss/contrastive_loss.py:10-19 / loss/lift_loss.py:13-22
@@ -273,6 +274,24 @@ int bevr_pack_kv(const float* k, const float* v, long long ld, long long pstride
                  int c, int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream);
 int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, long long pstride, int n_prob,
                     int N, int Np, int heads, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Key positions from the offset heads' outputs, in the attention's key order, and the adjoint (one launch each).
+ * Replaces model/SCA_deform_attn.py:248-277 (row split of the (b g) d (h n) w head output, tanh * range, + reference
+ * point -- or clamp --, per view) and model/TSA_deform_attn.py:170-196, plus the gather into the static key order.
+ *   off   [V][P][block] float   one view's head output per problem p = b * G + gi (P = B * G):
+ *           sca = 1: block = [S][S][D] (the fused head's channels-last output); component c (0 = y, 1 = x) of key
+ *                    n = hk * (S D) + w * D + d is element [(2 hk + c)][w][d]           (N = (S / 2) * S * D)
+ *           sca = 0: block = [N][2]   (y, x) per key-grid pixel
+ *   ref   [V][N][2] float (y, x)   reference points (SCA) / the regular grid (TSA), in the UNordered key index
+ *   order [V][N] int32 or NULL     static key order: output key n' is key order[v][n']
+ *   pos   [B][V][G][N][2] float    use_tanh = 1: tanh(off) * (sy, sx) + ref;   0: clamp(off + ref, -1, 1)
+ * backward: doff (off's shape) is WRITTEN (the order is a permutation: every element belongs to one key).
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_key_positions_fwd(const float* off, const float* ref, const int* order, float* pos, int V, int P, int G, int N,
+                           int sca, int S, int D, int use_tanh, float sy, float sx, void* stream);
+int bevr_key_positions_bwd(const float* off, const float* ref, const int* order, const float* dpos, float* doff, int V,
+                           int P, int G, int N, int sca, int S, int D, int use_tanh, float sy, float sx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Offset heads of the deformable attention blocks, fused per BEV pixel (model/SCA_deform_attn.py:56-77 conv_offset_m{v};

@@ -569,3 +569,69 @@ def test_sample_features_reads_bf16_features_as_they_are(shape):
     assert torch.equal(pb, pf) if c4 & (c4 - 1) == 0 else torch.allclose(pb, pf, rtol=1e-4, atol=1e-4 * pf.abs().max().item())
     # float atomics in a different order on the two runs: compare at the rounding of the bf16 result
     assert (fb.float() - ff).abs().max().item() <= 2.0 ** -7 * ff.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_tanh", [True, False])
+@pytest.mark.parametrize("cfg", [(2, 3, 1, 8, 3), (1, 6, 2, 12, 5), (3, 1, 1, 6, 1)])
+def test_key_positions_sca_equals_the_stock_op_chain(cfg, use_tanh):
+    """csrc/keypos.hip against the chain it replaces (model/SCA_deform_attn.py:248-277 restated with stock ops in
+    float64: "(b g) d (h n) w -> (b g) n h (w d)", tanh * range or clamp, + reference, gather into the key order),
+    forward and the gradient of the offsets."""
+    B, V, g, S, D = cfg
+    Hk, Wk = S // 2, S * D
+    N = Hk * Wk
+    gen = torch.Generator().manual_seed(S * D + V)
+    off = (torch.randn(V, B * g, S, S, D, generator=gen) * 1.5)
+    ref = torch.rand(V, N, 2, generator=gen) * 2.2 - 1.1
+    order = torch.stack([torch.randperm(N, generator=gen) for _ in range(V)])
+    sy, sx = 0.7 / (Hk - 1.0), 1.3 / (Wk - 1.0)
+    cot = torch.randn(B, V, g, N, 2, generator=gen)
+
+    o64 = off.double().requires_grad_(True)
+    outs = []
+    for v in range(V):
+        o = o64[v].reshape(B * g, Hk, 2, S, D).permute(0, 2, 1, 3, 4).reshape(B * g, 2, Hk, Wk)
+        if use_tanh:
+            o = o.tanh() * torch.tensor([sy, sx], dtype=torch.float64).reshape(1, 2, 1, 1)
+        p = o.permute(0, 2, 3, 1).reshape(B, g, N, 2) + ref[v].double()[None, None]
+        if not use_tanh:
+            p = p.clamp(-1.0, 1.0)
+        outs.append(p)
+    want = torch.stack(outs, 1).gather(3, order[None, :, None, :, None].expand(B, V, g, N, 2))
+    (want * cot.double()).sum().backward()
+
+    og = off.to(DEV).requires_grad_(True)
+    got = ops.key_positions(og, ref.to(DEV), order.to(DEV), B, g, sca_SD=(S, D), use_tanh=use_tanh, sy=sy, sx=sx)
+    (got * cot.to(DEV)).sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(og.grad.cpu().numpy(), o64.grad.numpy(), rtol=1e-4, atol=1e-6)
+    # without a key order
+    got2 = ops.key_positions(og.detach(), ref.to(DEV), None, B, g, sca_SD=(S, D), use_tanh=use_tanh, sy=sy, sx=sx)
+    np.testing.assert_allclose(got2.cpu().numpy(), torch.stack(outs, 1).detach().numpy(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_tanh", [True, False])
+def test_key_positions_tsa_equals_the_stock_op_chain(use_tanh):
+    """The TSA form (model/TSA_deform_attn.py:170-196): (y, x) offsets per key-grid pixel, + the regular grid."""
+    B, g, Hk, Wk = 2, 2, 7, 9
+    N = Hk * Wk
+    gen = torch.Generator().manual_seed(5)
+    off = torch.randn(1, B * g, N, 2, generator=gen)
+    grid = O.normalized_grid(Hk, Wk, torch.float32).reshape(1, N, 2)
+    order = torch.randperm(N, generator=gen)[None]
+    sy, sx = 2.0 / (Hk - 1.0), 2.0 / (Wk - 1.0)
+    cot = torch.randn(B, 1, g, N, 2, generator=gen)
+    o64 = off.double().requires_grad_(True)
+    p = o64[0].tanh() * torch.tensor([sy, sx], dtype=torch.float64) if use_tanh else o64[0]
+    p = p + grid.double()
+    if not use_tanh:
+        p = p.clamp(-1.0, 1.0)
+    want = p.index_select(1, order[0]).reshape(B, 1, g, N, 2)
+    (want * cot.double()).sum().backward()
+    og = off.to(DEV).requires_grad_(True)
+    got = ops.key_positions(og, grid.to(DEV), order.to(DEV), B, g, sca_SD=None, use_tanh=use_tanh, sy=sy, sx=sx)
+    (got * cot.to(DEV)).sum().backward()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(og.grad.cpu().numpy(), o64.grad.numpy(), rtol=1e-4, atol=1e-6)

@@ -202,11 +202,25 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_kernel(const T* __restr
 // The keys arrive in k-d order of their reference pixels (ops.split_key_order; the pinned keys cell-sorted behind
 // them), so a run of consecutive keys touches a compact patch of the feature map -- at the benchmark rig 512 keys x 4
 // taps fall on ~150 pixels.  A workgroup takes chunks of PCH_KEYS consecutive keys of one image: it finds the bounding
-// box of the chunk's taps, accumulates every tap inside a window of up to PCH_BYTES of it in LDS (ds_add_f32), and
-// flushes ONE global atomic per touched (pixel, channel): ~14x fewer global atomics than a scatter per key.  Taps
-// outside the window (a chunk that straddles the image) are scattered directly; taps on the hot corner are summed in
-// registers over all chunks of the workgroup as in sample_bwd_kernel<true>.
-constexpr int PCH_KEYS = 512, PCH_BYTES = 48 * 1024, PCH_WMAX = 32;
+// box of the chunk's taps, accumulates every tap inside a window of up to PCH_BYTES of it in LDS, and flushes ONE
+// global atomic per touched (pixel, channel): ~12x fewer global atomics than a scatter per key.  Taps outside the window
+// (a chunk that straddles the image) are scattered directly; taps on the hot corner are summed in registers over all
+// chunks of the workgroup as in sample_bwd_kernel<true>.
+//
+// The LDS cells are 64-bit FIXED POINT in units of gmax * 2^-40, gmax = the chunk's largest |dout| (found in the same
+// pass as the bounding box): ds_add_f32 retires ~3 clk per active lane (193 clk per wave instruction,
+// profiles/r02_lds_bench.txt) and owned 0.9 of the 3.2 ms of an SCA launch (racy read-modify-write probe: 2.35 ms);
+// ds_add_u64 takes 6.3 clk.  A tap value is at most gmax (bilinear weights <= 1) and a cell collects at most
+// 4 * PCH_KEYS of them: |cell| < 2^10 * 2^40; a contribution is rounded to 2^-40 of gmax -- far below float rounding --
+// and the integer sum is order-independent.
+constexpr int PCH_KEYS = 256, PCH_BYTES = 48 * 1024, PCH_WMAX = 32;
+
+// x / gmax * 2^40 as (hi: signed 32 bits, lo: unsigned 32 bits), t = x * 2^8 / gmax in [-256, 256]
+__device__ __forceinline__ unsigned long long to_fixed40(float t) {
+  const float h = floorf(t);
+  const unsigned lo = (unsigned)((t - h) * 4294967296.0f);   // t - h exact in f32, in [0, 1)
+  return ((unsigned long long)(unsigned)(int)h << 32) | lo;
+}
 
 template <typename T>
 __global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const T* __restrict__ feat,
@@ -214,12 +228,13 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const T* _
                                                                       const float* __restrict__ dout,
                                                                       float* __restrict__ dfeat, float* __restrict__ dpos,
                                                                       int nb, int Hi, int Wi, int C, int N, int pow2_group) {
-  __shared__ __attribute__((aligned(16))) float patch[PCH_BYTES / 4];   // the window; at the end the hot corner's partials
-  __shared__ int s_box[SB_THREADS / 64][4];
+  __shared__ __attribute__((aligned(16))) unsigned long long patch64[PCH_BYTES / 8];   // the window (fixed point)
+  float* patch = reinterpret_cast<float*>(patch64);                                     // at the end: the hot corner's partials
+  __shared__ int s_box[SB_THREADS / 64][5];
   const int c4n = C >> 2, tid = threadIdx.x;
   const int b = blockIdx.y;
   const int slots = SB_THREADS / c4n, slot = tid / c4n, c4 = tid % c4n;
-  const int pix_cap = PCH_BYTES / (C * 4);
+  const int pix_cap = PCH_BYTES / (C * 8);
   const size_t img = (size_t)b * Hi * Wi * C;
   const T* fb = feat + img + c4 * 4;
   float* gimg = dfeat + img;
@@ -245,21 +260,34 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const T* _
           if (in) { xlo = min(xlo, x); xhi = max(xhi, x); ylo = min(ylo, y); yhi = max(yhi, y); }
         }
     }
+    float gmax = 0.f;   // the chunk's largest |dout| (the main loop reads the rows again: L2 hits)
+    for (int u = tid; u < nk * c4n; u += SB_THREADS) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(dout + ((size_t)b * N + k0 + u / c4n) * C + (u % c4n) * 4);
+      gmax = fmaxf(gmax, fmaxf(fmaxf(fabsf(g4[0]), fabsf(g4[1])), fmaxf(fabsf(g4[2]), fabsf(g4[3]))));
+    }
 #pragma unroll
     for (int sh = 32; sh > 0; sh >>= 1) {
       xlo = min(xlo, __shfl_xor(xlo, sh)); xhi = max(xhi, __shfl_xor(xhi, sh));
       ylo = min(ylo, __shfl_xor(ylo, sh)); yhi = max(yhi, __shfl_xor(yhi, sh));
+      gmax = fmaxf(gmax, __shfl_xor(gmax, sh));
     }
-    if ((tid & 63) == 0) { s_box[tid >> 6][0] = xlo; s_box[tid >> 6][1] = xhi; s_box[tid >> 6][2] = ylo; s_box[tid >> 6][3] = yhi; }
+    if ((tid & 63) == 0) {
+      s_box[tid >> 6][0] = xlo; s_box[tid >> 6][1] = xhi; s_box[tid >> 6][2] = ylo; s_box[tid >> 6][3] = yhi;
+      s_box[tid >> 6][4] = __builtin_bit_cast(int, gmax);
+    }
     __syncthreads();   // also: the previous chunk's flush is complete
 #pragma unroll
     for (int w = 0; w < SB_THREADS / 64; ++w) {
       xlo = min(xlo, s_box[w][0]); xhi = max(xhi, s_box[w][1]); ylo = min(ylo, s_box[w][2]); yhi = max(yhi, s_box[w][3]);
+      gmax = fmaxf(gmax, __builtin_bit_cast(float, s_box[w][4]));
     }
-    const int pw = xhi >= xlo ? min(xhi - xlo + 1, PCH_WMAX) : 0;
+    // NaN / inf in dout: no finite unit -- every tap of the chunk takes the direct scatter (pw = 0)
+    const bool unit_ok = gmax > 0.f && gmax < 3.0e38f;
+    const float to_fix = unit_ok ? 256.0f / gmax : 0.f, from_fix = unit_ok ? gmax * 0x1p-40f : 0.f;
+    const int pw = (xhi >= xlo && unit_ok) ? min(xhi - xlo + 1, PCH_WMAX) : 0;
     const int ph = pw > 0 ? min(yhi - ylo + 1, pix_cap / pw) : 0;
     const int n_el = ph * pw * C;
-    for (int u = tid * 4; u < n_el; u += SB_THREADS * 4) *reinterpret_cast<f32x4*>(patch + u) = z;
+    for (int u = tid * 2; u < n_el; u += SB_THREADS * 2) *reinterpret_cast<u32x4*>(patch64 + u) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
 
     // ---- the chunk's keys, `slots` at a time (whole waves stay converged for the shuffles) ----
@@ -298,10 +326,11 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const T* _
             // element (pixel, c4, k) at pixel * C + ((k * c4n + c4 + 16 * pixel) mod C): the key slots of a wave land on
             // different bank groups when their pixels differ
             const int pix = py * pw + px;
-            float* pp = patch + pix * C;
+            unsigned long long* pp = patch64 + pix * C;
             const int rot = c4 + 16 * pix;
+            const float wt = wv[q] * to_fix;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(pp + ((k * c4n + rot) % C), g[k] * wv[q]);
+            for (int k = 0; k < 4; ++k) atomicAdd(pp + ((k * c4n + rot) % C), to_fixed40(g[k] * wt));
           } else {
             float* gp = gimg + ((size_t)y * Wi + x) * C + c4 * 4;
 #pragma unroll
@@ -332,11 +361,11 @@ __global__ __launch_bounds__(SB_THREADS) void sample_bwd_patch_kernel(const T* _
     // ---- flush the window: one atomic per touched (pixel, channel), 256-B rows ----
     for (int u = tid; u < ph * pw * c4n; u += SB_THREADS) {
       const int pix = u / c4n, cc = u % c4n;
-      const float* pp = patch + pix * C;
+      const unsigned long long* pp = patch64 + pix * C;
       const int rot = cc + 16 * pix;
       float a[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) a[k] = pp[(k * c4n + rot) % C];
+      for (int k = 0; k < 4; ++k) a[k] = (float)(long long)pp[(k * c4n + rot) % C] * from_fix;   // the cell converted whole
       if (a[0] != 0.f || a[1] != 0.f || a[2] != 0.f || a[3] != 0.f) {
         float* gp = gimg + ((size_t)(ylo + pix / pw) * Wi + xlo + pix % pw) * C + cc * 4;
 #pragma unroll

@@ -430,7 +430,11 @@ __global__ __launch_bounds__(MAXT) void attn_cell_bwd_q_kernel(
       if (more) {
 #pragma unroll
         for (int k = 0; k < L::NST; ++k) {
+#if defined(BEVR_VARIANT) && BEVR_VARIANT == 4   // timing probe: every step re-reads the first steps' (cache-hot) data
+          st_src[k] += (step < 8 ? st_inc[k] : 0);
+#else
           st_src[k] += st_inc[k];
+#endif
           st[k] = gload16(st_src[k]);
         }
       }

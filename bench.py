@@ -384,7 +384,8 @@ def main():
         # (forward); + the map's gradient once (backward).  `traffic` = what the PMC counters saw (the backward's
         # scatter is memory-side float atomics, 4 taps per key)
         roof_hbm = []
-        for k in ("bevr_sample_fwd", "bevr_sample_bwd"):
+        # bevr_kv_project: sampling + K | V projection + operand packing in one pass (feature map in, packed operands out)
+        for k in ("bevr_kv_project", "bevr_sample_fwd", "bevr_sample_bwd"):
             if k in ktimes and ktimes[k]["ms"] > 0:
                 v = ktimes[k]
                 gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9

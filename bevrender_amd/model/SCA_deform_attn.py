@@ -137,13 +137,22 @@ class SCADeformableAttention(nn.Module):
             pos = torch.cat((pos[:, :cell_split], pos[:, cell_split:].gather(1, dyn[..., None].expand(-1, -1, 2))), 1)
         else:
             cell_split = None
-        xs = ops.sample_features(x.reshape(B * V, C, Hi, Wi), pos, g)            # (B*V, N, C)
         # proj_k and proj_v as ONE GEMM over the sampled features (same arithmetic per output column; the features are
         # read once instead of twice)
-        kv = F.linear(xs, torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0),
-                      torch.cat((self.proj_k.bias, self.proj_v.bias), 0))
-        o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
-                               precision=self.precision, kv=kv, cell_split=cell_split)   # (B*V, S*S, C)
+        Wkv = torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0)
+        bkv = torch.cat((self.proj_k.bias, self.proj_v.bias), 0)
+        xf = x.reshape(B * V, C, Hi, Wi)
+        if x.is_cuda and ops.kv_source_supported(C, self.n_heads, g, self.precision):
+            # sampling, projection and operand packing as one kernel (csrc/kvproj.hip): neither the sampled features
+            # nor the projected rows reach HBM.  The channels-last view of the backbone's output is read as it is
+            feat = (xf if xf.dtype == torch.bfloat16 else xf.float()).permute(0, 2, 3, 1).contiguous()
+            o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
+                                   precision=self.precision, kv_source=(feat, Wkv, bkv), cell_split=cell_split)
+        else:
+            xs = ops.sample_features(xf, pos, g)                                     # (B*V, N, C)
+            kv = F.linear(xs, Wkv, bkv)
+            o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
+                                   precision=self.precision, kv=kv, cell_split=cell_split)   # (B*V, S*S, C)
         o = o.reshape(B, V, S * S, C).permute(0, 2, 1, 3).reshape(B, S * S, V * C)
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
         return out.permute(0, 2, 1).reshape(B, C, S, S), wandb_log_dict

@@ -105,13 +105,20 @@ class TSADeformableAttention(nn.Module):
             x = query
         B, C, H, W = x.shape
         pos = self.key_positions(query)
-        xs = ops.sample_features(x, pos, self.n_groups)                                  # (B, N, C)
         # proj_k and proj_v as ONE GEMM over the sampled features (same arithmetic per output column; the features are
         # read once instead of twice)
-        kv = F.linear(xs, torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0),
-                      torch.cat((self.proj_k.bias, self.proj_v.bias), 0))
-        o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
-                               views=1, precision=self.precision, kv=kv)                 # (B, H*W, C)
+        Wkv = torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0)
+        bkv = torch.cat((self.proj_k.bias, self.proj_v.bias), 0)
+        if x.is_cuda and ops.kv_source_supported(C, self.n_heads, self.n_groups, self.precision):
+            # sampling, projection and operand packing as one kernel (csrc/kvproj.hip)
+            feat = (x if x.dtype == torch.bfloat16 else x.float()).permute(0, 2, 3, 1).contiguous()
+            o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
+                                   views=1, precision=self.precision, kv_source=(feat, Wkv, bkv))
+        else:
+            xs = ops.sample_features(x, pos, self.n_groups)                              # (B, N, C)
+            kv = F.linear(xs, Wkv, bkv)
+            o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
+                                   views=1, precision=self.precision, kv=kv)             # (B, H*W, C)
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
         out = out.permute(0, 2, 1).reshape(B, C, H, W)
         return out, wandb_log_dict

@@ -330,14 +330,25 @@ class _AttnCore(torch.autograd.Function):
     backward passes of both use the final LSE and delta and accumulate into the same dQ and d(table)."""
 
     @staticmethod
-    def forward(ctx, Qp, kv, key_a, key_b, Tt, geom: AttnGeom, split: int):
-        _require_gpu(Qp, kv, key_a, key_b, Tt)
+    def forward(ctx, Qp, kv, key_a, key_b, Tt, geom: AttnGeom, split: int, feat=None, spos=None, Wkv=None, bkv=None):
+        """kv (B', N, 2C) projected rows -- or None with the K | V SOURCE instead: feat (B', Hi, Wi, C) channels-last
+        feature map (float or bf16), spos (B', N, 2) sampling positions, Wkv (2C, C), bkv (2C,) the proj_k | proj_v
+        weights: the operands are then produced by bevr_kv_project (csrc/kvproj.hip: sample -> project -> packed layouts
+        in one pass, 16-bit operand modes)."""
+        _require_gpu(Qp, kv, key_a, key_b, Tt, feat, spos, Wkv, bkv)
         L = _lib.lib()
         ed = _edtype(geom.precision)
         x3 = geom.precision == _lib.PREC_BF16X3
         Qe = _split_rows(Qp.float()) if x3 else Qp.to(ed).contiguous()
-        kv = kv.float().contiguous()
-        N, C2 = kv.shape[1], kv.shape[-1]
+        fused = kv is None
+        if fused:
+            feat, spos = feat.contiguous(), spos.float().contiguous()
+            N, C2 = spos.shape[1], 2 * feat.shape[-1]
+            W_e = Wkv.detach().to(ed).contiguous()
+            b_f = None if bkv is None else bkv.detach().float().contiguous()
+        else:
+            kv = kv.float().contiguous()
+            N, C2 = kv.shape[1], kv.shape[-1]
         c = C2 // 2 // geom.heads
         dev = Qp.device
         segs = []
@@ -361,9 +372,18 @@ class _AttnCore(torch.autograd.Function):
             Ve = torch.empty_like(Ke)
             Vt = torch.empty(g.n_prob, g.heads, HEAD_DIM, g.Np, device=dev, dtype=ed)
             Kt = torch.empty_like(Vt) if need_bwd else None
-            kp = kv.data_ptr() + sg.n0 * C2 * 4
-            _lib.check(L.bevr_pack_kv(C.c_void_p(kp), C.c_void_p(kp + 2 * C2), C2, N, g.n_prob, g.N, g.Np, g.heads, c,
-                                      g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _stream()), "bevr_pack_kv")
+            if fused:
+                nb, Hi, Wi, Cc = feat.shape
+                _lib.check(KERNEL_TIMER.run(
+                    "bevr_kv_project", 0.0, L.bevr_kv_project, _ptr(feat), int(feat.dtype == torch.bfloat16),
+                    C.c_void_p(spos.data_ptr() + sg.n0 * 8), N, _ptr(W_e), _ptr(b_f), nb, Hi, Wi, Cc, g.N, g.Np, g.heads, c,
+                    g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _stream(),
+                    nbytes=float(feat.numel() * feat.element_size() + 8 * nb * g.N + (4 if need_bwd else 3) * Ke.numel() * 2)),
+                    "bevr_kv_project")
+            else:
+                kp = kv.data_ptr() + sg.n0 * C2 * 4
+                _lib.check(L.bevr_pack_kv(C.c_void_p(kp), C.c_void_p(kp + 2 * C2), C2, N, g.n_prob, g.N, g.Np, g.heads, c,
+                                          g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _stream()), "bevr_pack_kv")
             ka = F.pad(key_a[:, sg.n0:sg.n0 + g.N], (0, g.Np - g.N)).contiguous()
             kb = F.pad(key_b[:, sg.n0:sg.n0 + g.N], (0, g.Np - g.N)).contiguous()
             d = g.desc()
@@ -385,7 +405,12 @@ class _AttnCore(torch.autograd.Function):
         # split mode: the packed V is not readable as numbers; the norm bound of the backward's scales from the rows
         ctx.vmax = kv[..., C2 // 2:].reshape(kv.shape[0], N, geom.heads, c).norm(dim=-1).max() if x3 and need_bwd else None
         ctx.segs = segs
-        ctx.kv_shape = kv.shape
+        ctx.kv_shape = (geom.n_prob, N, C2)
+        ctx.fused = fused
+        if fused:
+            ctx.n_seg_saved = len(saved)
+            saved += [feat, spos, Wkv] + ([bkv] if bkv is not None else [])
+            ctx.has_bias = bkv is not None
         ctx.save_for_backward(Qe, pair, O, LSE, *saved)
         return O
 
@@ -393,6 +418,9 @@ class _AttnCore(torch.autograd.Function):
     def backward(ctx, dO):
         geom: AttnGeom = ctx.geom
         Qe, pair, O, LSE, *saved = ctx.saved_tensors
+        if ctx.fused:
+            src = saved[ctx.n_seg_saved:]
+            saved = saved[:ctx.n_seg_saved]
         L = _lib.lib()
         ed = _edtype(geom.precision)
         dO = dO.contiguous()
@@ -483,12 +511,24 @@ class _AttnCore(torch.autograd.Function):
         if f16:   # undo the cotangent's power-of-two scale
             inv = 1.0 / sdo
             dQ, dkv, da, db, dT = dQ * inv, dkv * inv, da * inv, db * inv, dT * inv
-        return dQ, dkv, da, db, dT, None, None
+        if not ctx.fused:
+            return dQ, dkv, da, db, dT, None, None, None, None, None, None
+        # adjoint of the fused K | V source in its unfused form: the projection's GEMMs on the float samples (recomputed:
+        # the forward never wrote them) and the sampler's scatter
+        feat, spos, Wkv = src[0], src[1], src[2]
+        xs = _Sample.sample(feat, spos)                                              # (B', N, C) float
+        d2 = dkv.reshape(-1, dkv.shape[-1])
+        dW = d2.t() @ xs.reshape(-1, xs.shape[-1]) if ctx.needs_input_grad[9] else None
+        dbias = d2.sum(0) if ctx.has_bias and ctx.needs_input_grad[10] else None
+        dxs = (d2 @ Wkv.float()).reshape(xs.shape)
+        del xs
+        dfeat, dspos = _Sample.scatter(feat, spos, dxs, ctx.needs_input_grad[7])
+        return dQ, None, da, db, dT, None, None, dfeat, dspos, dW, dbias
 
 
 def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Optional[torch.Tensor], pos: torch.Tensor,
                    rpe_table: torch.Tensor, *, heads: int, groups: int, views: int, precision: int,
-                   kv: Optional[torch.Tensor] = None, cell_split: Optional[int] = None) -> torch.Tensor:
+                   kv: Optional[torch.Tensor] = None, cell_split: Optional[int] = None, kv_source=None) -> torch.Tensor:
     """Fused attention of the BEV query against sampled keys.
 
     query (B, C, S, S) layer-normed BEV query (used raw as Q); kproj, vproj (B*views, N, C) projected
@@ -497,17 +537,31 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     cell_split: keys [cell_split, N) are CELL-SORTED (cell_order: the caller ordered them by rpe-table cell) and go
     through the cell kernels (bias as an MFMA), keys [0, cell_split) through the region kernels; None = N (no cell
     segment).  Any split gives the same result; it only decides the speed.
+    kv_source = (feat, Wkv, bkv) instead of kproj / vproj / kv: feat (B*views, Hi, Wi, C) the channels-last feature map
+    (float or bf16) the keys are sampled from AT `pos`, Wkv (2C, C) / bkv (2C,) the proj_k | proj_v weights: sampling,
+    projection and operand packing run as one kernel (csrc/kvproj.hip; groups == 1, 16-bit operand modes -- see
+    kv_source_supported).
     Returns (B*views, S*S, C): per view softmax(QK^T c^-0.5 + bias) V, rows in i*S + j order.
     Replaces model/SCA_deform_attn.py:304-413 / model/TSA_deform_attn.py:220-333.
     """
-    if kv is None:
-        kv = torch.cat((kproj, vproj), -1)
-    elif kproj is not None or vproj is not None:
-        raise ValueError("pass either kproj and vproj, or kv")
     B, Cc, S, _ = query.shape
-    Bp, N, C2 = kv.shape
-    if C2 != 2 * Cc:
-        raise ValueError(f"K | V rows must have 2 x {Cc} channels, got {C2}")
+    if kv_source is not None:
+        if kv is not None or kproj is not None or vproj is not None:
+            raise ValueError("pass kv_source alone")
+        feat, Wkv, bkv = kv_source
+        if not kv_source_supported(Cc, heads, groups, precision):
+            raise ValueError("kv_source needs groups == 1, a 16-bit operand mode and C % 16 == 0")
+        Bp, N = pos.shape[0], pos.shape[1]
+        if feat.shape[0] != Bp or feat.shape[-1] != Cc or tuple(Wkv.shape) != (2 * Cc, Cc):
+            raise ValueError("kv_source shapes: feat (B*views, Hi, Wi, C), Wkv (2C, C)")
+    else:
+        if kv is None:
+            kv = torch.cat((kproj, vproj), -1)
+        elif kproj is not None or vproj is not None:
+            raise ValueError("pass either kproj and vproj, or kv")
+        Bp, N, C2 = kv.shape
+        if C2 != 2 * Cc:
+            raise ValueError(f"K | V rows must have 2 x {Cc} channels, got {C2}")
     c = Cc // heads
     split = N if cell_split is None else int(cell_split)
     if not 0 <= split <= N:
@@ -521,8 +575,19 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     Qp = pack_query(query.float(), heads)
     a, b = key_coords(pos.float(), S, geom.Wt, N)
     Tt = pack_table(rpe_table.float(), geom)
-    O = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split)
+    if kv_source is not None:
+        O = _AttnCore.apply(Qp, None, a, b, Tt, geom, split, feat, pos.float(), Wkv, bkv)
+    else:
+        O = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split, None, None, None, None)
     return unpack_out(O, S, c)
+
+
+def kv_source_supported(C: int, heads: int, groups: int, precision: int) -> bool:
+    """Can the K | V operands come from the fused sample -> project -> pack kernel (csrc/kvproj.hip)?  BEVR_FUSED_KV=0
+    turns it off (the unfused chain sample -> rocBLAS -> bevr_pack_kv is then used; same results to the operands'
+    rounding)."""
+    return (groups == 1 and precision in (_lib.PREC_BF16, _lib.PREC_F16) and C % 16 == 0 and C <= 256
+            and C % heads == 0 and C // heads <= 32 and os.environ.get("BEVR_FUSED_KV", "1") != "0")
 
 
 class _Sample(torch.autograd.Function):
@@ -534,6 +599,17 @@ class _Sample(torch.autograd.Function):
     def forward(ctx, feat, pos):
         _require_gpu(feat, pos)
         feat, pos = feat.contiguous(), pos.contiguous()
+        out = _Sample.sample(feat, pos)
+        ctx.save_for_backward(feat, pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, pos = ctx.saved_tensors
+        return _Sample.scatter(feat, pos, dout, ctx.needs_input_grad[0])
+
+    @staticmethod
+    def sample(feat, pos):
         nb, Hi, Wi, Cc = feat.shape
         N = pos.shape[1]
         out = torch.empty(nb, N, Cc, device=feat.device, dtype=torch.float32)
@@ -545,12 +621,10 @@ class _Sample(torch.autograd.Function):
                                     _ptr(out), nb, Hi, Wi, Cc, N, _stream(),
                                     nbytes=4.0 * nb * (Hi * Wi * Cc * (0.5 if bf else 1.0) + N * Cc + 2 * N)),
                    "bevr_sample_fwd")
-        ctx.save_for_backward(feat, pos)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        feat, pos = ctx.saved_tensors
+    def scatter(feat, pos, dout, need_dfeat=True):
         nb, Hi, Wi, Cc = feat.shape
         N = pos.shape[1]
         dout = dout.contiguous()
@@ -566,7 +640,7 @@ class _Sample(torch.autograd.Function):
                                     nbytes=4.0 * nb * (N * Cc + (1.5 if bf else 2.0) * Hi * Wi * Cc + 4 * N)),
                    "bevr_sample_bwd")
         # autograd wants the input's dtype; the cast is skipped when nobody reads the map's gradient
-        return (dfeat.to(feat.dtype) if bf and ctx.needs_input_grad[0] else dfeat if not bf else None), dpos
+        return (dfeat.to(feat.dtype) if bf and need_dfeat else dfeat if not bf else None), dpos
 
 
 def sample_features(feat_nchw: torch.Tensor, pos: torch.Tensor, groups: int) -> torch.Tensor:

@@ -23,6 +23,7 @@
  *   bevr_pack_kv/unpack_dkv model/SCA_deform_attn.py:312-321 (projection outputs -> per-head operand layouts)
  *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
  *   bevr_offset_head_fwd/bwd  model/SCA_deform_attn.py:56-77, model/TSA_deform_attn.py:54-68 (offset heads, fused)
+ *   bevr_kv_project         model/SCA_deform_attn.py:290-321, model/TSA_deform_attn.py:210-236 (sample + proj_k | proj_v + pack)
  *   bevr_key_positions_fwd/bwd  model/SCA_deform_attn.py:248-277, model/TSA_deform_attn.py:170-196 (row split, tanh range, + ref, key order)
  *   bevr_affine_warp_fwd/bwd  model/encoder.py:413-466 (project_history_bev_feat: torchvision F.affine, twice)
  *   bevr_corr_fwd/bwd       train.py:554 (2 - 2 cam map^T) and the pairwise distance inside
@@ -274,6 +275,23 @@ int bevr_pack_kv(const float* k, const float* v, long long ld, long long pstride
                  int c, int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream);
 int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, long long pstride, int n_prob,
                     int N, int Np, int heads, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K | V operands straight from the feature map (16-bit operand modes): bilinear sampling at `pos` -> proj_k | proj_v
+ * as one 1x1 GEMM on the matrix cores -> the packed layouts below, in one pass; the sampled features and the projected
+ * rows never reach HBM.  Replaces bevr_sample_fwd -> GEMM -> bevr_pack_kv, i.e. F.grid_sample + proj_k / proj_v + the
+ * per-head reshapes of model/SCA_deform_attn.py:290-321, model/TSA_deform_attn.py:210-236 (channel groups == 1).
+ *   feat [nb][Hi][Wi][C]  float, or bf16 bits if feat_bf16 (channels-last)
+ *   pos  (y, x) of key n of problem b at pos[(b * pos_pstride + n) * 2]   (a key segment: pass pos + 2 n0)
+ *   Wkv  [2C][C] E (E = bf16 / fp16 per `precision`: the caller rounds the float weights once), rows 0..C-1 = proj_k
+ *   bkv  [2C] float or NULL
+ *   outputs as bevr_pack_kv: Kr, Vr [nb][heads][Np][32] E, Kt (or NULL), Vt [nb][heads][32][Np] E; keys N..Np-1 zero.
+ *   C = heads * c, c <= 32, C % 16 == 0, C <= 256; Np % 64 == 0.
+ * The adjoint stays unfused: bevr_unpack_dkv -> GEMMs -> bevr_sample_bwd on samples recomputed with bevr_sample_fwd.
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_kv_project(const void* feat, int feat_bf16, const float* pos, long long pos_pstride, const void* Wkv,
+                    const float* bkv, int nb, int Hi, int Wi, int C, int N, int Np, int heads, int c, int precision,
+                    void* Kr, void* Vr, void* Kt, void* Vt, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Key positions from the offset heads' outputs, in the attention's key order, and the adjoint (one launch each).

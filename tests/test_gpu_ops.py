@@ -635,3 +635,93 @@ def test_key_positions_tsa_equals_the_stock_op_chain(use_tanh):
     (got * cot.to(DEV)).sum().backward()
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(og.grad.cpu().numpy(), o64.grad.numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [_lib.PREC_BF16, _lib.PREC_F16])
+@pytest.mark.parametrize("feat_bf16", [False, True])
+@pytest.mark.parametrize("shape", [(2, 64, 2, 12, 20, 300), (1, 64, 4, 9, 7, 129), (2, 32, 1, 6, 10, 64), (1, 48, 2, 8, 8, 70)])
+def test_kv_project_equals_sample_gemm_pack(shape, feat_bf16, prec):
+    """csrc/kvproj.hip (sampling -> proj_k | proj_v -> packed operands in one pass) against the chain it replaces:
+    bevr_sample_fwd -> the GEMM in float64 on the E-rounded samples and weights -> rounding to E -> the layouts of
+    bevr_pack_kv.  The kernel accumulates the same products in f32: agreement to the last place or two of E; padded keys
+    and padded head channels exactly zero; a key segment (pointer offset + problem stride) as ops._AttnCore passes it."""
+    import ctypes as C
+    Bp, Cc, h, Hi, Wi, N = shape
+    c = Cc // h
+    ed = torch.bfloat16 if prec == _lib.PREC_BF16 else torch.float16
+    gen = torch.Generator().manual_seed(N + Cc)
+    feat = torch.randn(Bp, Hi, Wi, Cc, generator=gen)
+    feat = (feat.to(torch.bfloat16) if feat_bf16 else feat).to(DEV)
+    pos = (torch.rand(Bp, N, 2, generator=gen) * 2.4 - 1.2).to(DEV)
+    W = (torch.randn(2 * Cc, Cc, generator=gen) / Cc ** 0.5).to(DEV)
+    bias = torch.randn(2 * Cc, generator=gen).to(DEV)
+    n0 = 5                                                # a segment: keys [n0, N)
+    Ns = N - n0
+    Np = 64 * ((Ns + 63) // 64)
+    mk = lambda *s: torch.full(s, 7.0, device=DEV, dtype=ed)
+    Kr, Vr, Kt, Vt = mk(Bp, h, Np, 32), mk(Bp, h, Np, 32), mk(Bp, h, 32, Np), mk(Bp, h, 32, Np)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    We = W.to(ed).contiguous()
+    rc = _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), C.c_void_p(pos.data_ptr() + n0 * 8), N, p(We), p(bias), Bp, Hi,
+                                    Wi, Cc, Ns, Np, h, c, prec, p(Kr), p(Vr), p(Kt), p(Vt), st)
+    assert rc == 0
+    xs = ops._Sample.sample(feat, pos)[:, n0:]                              # float samples, the unfused kernel
+    kv = (xs.to(ed).double() @ We.double().t() + bias.double()).float()     # products of E values, exact accumulation
+    Kw = ops.pack_keys(kv[..., :Cc].contiguous(), h).to(ed)
+    Vw = ops.pack_keys(kv[..., Cc:].contiguous(), h).to(ed)
+    ulp = 2.0 ** -8 if prec == _lib.PREC_BF16 else 2.0 ** -11
+    for got, want in ((Kr, Kw), (Vr, Vw), (Kt, ops._perm_t(Kw)), (Vt, ops._perm_t(Vw))):
+        g, w = got.float(), want.float()
+        assert (g - w).abs().max().item() <= 2.0 * ulp * max(w.abs().max().item(), 1.0)
+        assert torch.equal(g == 0, w == 0) or ((g - w).abs()[(g == 0) != (w == 0)] < 1e-3).all()
+    assert (Kr[:, :, Ns:] == 0).all() and (Vt[..., Ns:] == 0).all()         # padded keys: zeros, no bias
+    if c < 32:
+        assert (Kr[..., c:] == 0).all() and (Vt[:, :, c:] == 0).all()       # padded head channels
+    # no transposed K requested (forward-only call)
+    Kr2, Vr2, Vt2 = mk(Bp, h, Np, 32), mk(Bp, h, Np, 32), mk(Bp, h, 32, Np)
+    assert _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), C.c_void_p(pos.data_ptr() + n0 * 8), N, p(We), p(bias), Bp,
+                                      Hi, Wi, Cc, Ns, Np, h, c, prec, p(Kr2), p(Vr2), None, p(Vt2), st) == 0
+    assert torch.equal(Kr2, Kr) and torch.equal(Vt2, Vt)
+    # argument contract: f32-layout modes are refused
+    assert _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), p(pos), N, p(We), p(bias), Bp, Hi, Wi, Cc, Ns, Np, h, c,
+                                      _lib.PREC_F32, p(Kr), p(Vr), None, p(Vt), st) == -3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", [_lib.PREC_BF16, _lib.PREC_F16])
+def test_attention_core_with_fused_kv_source_matches_the_unfused_chain(prec):
+    """ops.attention_core(kv_source=...) against sample_features -> F.linear -> attention_core(kv=...): the same
+    forward to the operands' rounding, and every gradient (feature map, sampling + bias positions, projection weights
+    and bias, query, table) -- the fused path's adjoint is the unfused chain on recomputed samples."""
+    B, V, Cc, h, S, D, Hi, Wi = 1, 2, 64, 2, 10, 3, 12, 20
+    N = (S // 2) * S * D
+    gen = torch.Generator().manual_seed(77)
+    query = torch.randn(B, Cc, S, S, generator=gen)
+    feat = torch.randn(B * V, Hi, Wi, Cc, generator=gen)
+    pos = torch.rand(B * V, N, 2, generator=gen) * 2.2 - 1.1
+    W = torch.randn(2 * Cc, Cc, generator=gen) / Cc ** 0.5
+    bias = torch.randn(2 * Cc, generator=gen) * 0.1
+    table = torch.randn(h, 2 * S - 1, 2 * S * D - 1, generator=gen) * 0.3
+    cot = torch.randn(B * V, S * S, Cc, generator=gen).to(DEV)
+    res = []
+    for fused in (True, False):
+        ins = [t.clone().to(DEV).requires_grad_(True) for t in (query, feat, pos, W, bias, table)]
+        q, f, p_, w, b_, t = ins
+        if fused:
+            out = ops.attention_core(q, None, None, p_, t, heads=h, groups=1, views=V, precision=prec,
+                                     kv_source=(f, w, b_), cell_split=N // 2)
+        else:
+            xs = ops._Sample.apply(f, p_)
+            out = ops.attention_core(q, None, None, p_, t, heads=h, groups=1, views=V, precision=prec,
+                                     kv=F.linear(xs, w, b_), cell_split=N // 2)
+        out.backward(cot)
+        res.append((out.detach(), [x.grad for x in ins]))
+    (of, gf), (ou, gu) = res
+    lim = 2e-2 if prec == _lib.PREC_BF16 else 3e-3
+    assert rel_err(of.cpu(), ou.cpu()) < lim
+    for n, a, b in zip(("query", "feat", "pos", "W", "bias", "table"), gf, gu):
+        e = rel_err(a.cpu(), b.cpu())
+        print(f"[fused kv prec={prec}] grad {n} rel diff {e:.2e}")
+        assert e < 2.5 * lim, f"grad {n}: {e:.3e}"

@@ -11,7 +11,7 @@ import sys
 
 root, batch, cmd, sha = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
 NAMES = {"attn_fwd_kernel": "bevr_attn_fwd", "attn_bwd_q_kernel": "bevr_attn_bwd_q", "attn_bwd_k_win_kernel": "bevr_attn_bwd_k",
-         "attn_bwd_k_gather_kernel": "bevr_attn_bwd_k", "sample_fwd_kernel": "bevr_sample_fwd", "sample_bwd_kernel": "bevr_sample_bwd", "sample_bwd_patch_kernel": "bevr_sample_bwd",
+         "attn_bwd_k_gather_kernel": "bevr_attn_bwd_k", "sample_fwd_kernel": "bevr_sample_fwd", "sample_bwd_kernel": "bevr_sample_bwd", "sample_bwd_patch_kernel": "bevr_sample_bwd", "kv_project_kernel": "bevr_kv_project",
          "attn_cell_fwd_kernel": "bevr_attn_cell_fwd", "attn_cell_bwd_q_kernel": "bevr_attn_cell_bwd_q",
          "attn_cell_bwd_k_kernel": "bevr_attn_cell_bwd_k"}
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -21,7 +21,7 @@ for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"(attn_\w+_kernel|sample_\w+_kernel)", r["Kernel_Name"])
+            m = re.search(r"(attn_\w+_kernel|sample_\w+_kernel|kv_project_kernel)", r["Kernel_Name"])
             if not m or m.group(1) not in NAMES:
                 continue
             k = NAMES[m.group(1)]

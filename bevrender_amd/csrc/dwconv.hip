@@ -110,6 +110,136 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(DwGeom g, const float
   }
 }
 
+// ---- channels-last fast paths (C % 4 == 0): the MLP's 3x3 on the 4x-expanded BEV (C = 256, 328 MB per tensor at the
+// benchmark size) is two thirds of the depthwise time.  The generic kernel above reads every input element k*k times
+// through L1 / L2 and pays four 64-bit divisions per element; here a thread owns 4 channels x DW_XT consecutive pixels of
+// one row: (DW_XT + K - 1) 16-byte loads per filter row feed DW_XT outputs (3.75 loads per output at K = 3 against 9),
+// filter taps in registers.
+constexpr int DW_XT = 8;
+
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_fwd_nhwc4_kernel(int B, int H, int W, int C, const float* __restrict__ x,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int flip) {
+  constexpr int P = K / 2;
+  const int c4n = C >> 2, n_xt = (W + DW_XT - 1) / DW_XT;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * H * n_xt * c4n) return;
+  const int c4 = (int)(idx % c4n);
+  long t = idx / c4n;
+  const int xt = (int)(t % n_xt);
+  t /= n_xt;
+  const int yy = (int)(t % H), b = (int)(t / H);
+  const int x0 = xt * DW_XT, c0 = c4 * 4;
+  f32x4 wv[K * K];   // wv[tap][channel of the quad]
+#pragma unroll
+  for (int tp = 0; tp < K * K; ++tp) {
+    const int src = flip ? K * K - 1 - tp : tp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[tp][k] = w[(long)(c0 + k) * K * K + src];
+  }
+  f32x4 acc[DW_XT];
+  const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < DW_XT; ++i) acc[i] = b4;
+  const float* xb = x + ((long)b * H * W) * C + c0;
+#pragma unroll
+  for (int dy = 0; dy < K; ++dy) {
+    const int iy = yy + dy - P;
+    if (iy < 0 || iy >= H) continue;
+    f32x4 row[DW_XT + K - 1];
+#pragma unroll
+    for (int i = 0; i < DW_XT + K - 1; ++i) {
+      const int ix = x0 + i - P;
+      row[i] = (ix >= 0 && ix < W) ? *reinterpret_cast<const f32x4*>(xb + ((long)iy * W + ix) * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < DW_XT; ++i)
+#pragma unroll
+      for (int dx = 0; dx < K; ++dx) acc[i] += row[i + dx] * wv[dy * K + dx];
+  }
+  float* yb = y + (((long)b * H + yy) * W) * C + c0;
+#pragma unroll
+  for (int i = 0; i < DW_XT; ++i)
+    if (x0 + i < W) *reinterpret_cast<f32x4*>(yb + (long)(x0 + i) * C) = acc[i];
+}
+
+// weight / bias gradient, channels-last.  A wave takes one image row: lane = (channel quad, x segment) -- 64 quads at
+// C = 256, 16 quads x 4 segments at C = 64 -- and slides a K x K window of 16-byte loads along its segment with the
+// K*K*4 partial sums in registers; the 4 waves of a workgroup (4 rows) and the x segments are summed through LDS, and
+// one atomic per (channel, tap) leaves the WORKGROUP: 4-16x fewer atomics onto the same C*K*K addresses than one per
+// row line.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_w_nhwc4_kernel(int B, int H, int W, int C, const float* __restrict__ x,
+                                                                 const float* __restrict__ dy_, float* __restrict__ dw,
+                                                                 float* __restrict__ dbias) {
+  constexpr int P = K / 2, NV = K * K + 1;            // partial sums per lane: taps + bias, each a channel quad
+  __shared__ f32x4 red[4][NV][64];
+  const int c4n = C >> 2;
+  const int qpw = min(c4n, 64), n_seg = 64 / qpw;     // quads per wave, x segments per wave (c4n is a power of two or >= 64)
+  const int n_qg = (c4n + qpw - 1) / qpw;             // quad groups (C > 256: several workgroups per row block)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int qg = blockIdx.x % n_qg;
+  const long rb = blockIdx.x / n_qg;                  // row block: 4 consecutive rows of one image
+  const int n_rb = (H + 3) / 4;
+  const int b = (int)(rb / n_rb), yy = (int)(rb % n_rb) * 4 + wave;
+  const int quad = qg * qpw + lane % qpw, seg = lane / qpw;
+  const bool on = yy < H && quad < c4n;
+  const int c0 = quad * 4;
+  const int seg_w = (W + n_seg - 1) / n_seg, xa = seg * seg_w, xe = min(W, xa + seg_w);
+  f32x4 acc[NV];
+#pragma unroll
+  for (int tp = 0; tp < NV; ++tp) acc[tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    const float* xb = x + ((long)b * H * W) * C + c0;
+    const float* gb = dy_ + (((long)b * H + yy) * W) * C + c0;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 win[K][K];                                  // win[dy][j] = x[yy + dy - P][xx + j - P]
+#pragma unroll
+    for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int iy = yy + dy - P, ix = xa + j - P;
+        win[dy][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? *reinterpret_cast<const f32x4*>(xb + ((long)iy * W + ix) * C) : z;
+      }
+    for (int xx = xa; xx < xe; ++xx) {
+      const f32x4 gq = *reinterpret_cast<const f32x4*>(gb + (long)xx * C);
+      acc[K * K] += gq;
+#pragma unroll
+      for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[dy * K + j] += gq * win[dy][j];
+      const int nx = xx + 1 + P;                      // shift the window one pixel to the right
+#pragma unroll
+      for (int dy = 0; dy < K; ++dy) {
+#pragma unroll
+        for (int j = 0; j + 1 < K; ++j) win[dy][j] = win[dy][j + 1];
+        const int iy = yy + dy - P;
+        win[dy][K - 1] = (iy >= 0 && iy < H && nx < W) ? *reinterpret_cast<const f32x4*>(xb + ((long)iy * W + nx) * C) : z;
+      }
+    }
+  }
+#pragma unroll
+  for (int tp = 0; tp < NV; ++tp) red[wave][tp][lane] = acc[tp];
+  __syncthreads();
+  // (quad of this workgroup, value): sum over the 4 waves and the x segments, one atomic each
+  for (int u = threadIdx.x; u < qpw * NV; u += 256) {
+    const int q = u % qpw, tp = u / qpw;
+    if (qg * qpw + q >= c4n) continue;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int wv = 0; wv < 4; ++wv)
+      for (int sg = 0; sg < n_seg; ++sg) sum += red[wv][tp][sg * qpw + q];
+    const int cc = (qg * qpw + q) * 4;
+    if (tp < K * K) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(dw + (long)(cc + k) * K * K + tp, sum[k]);
+    } else if (dbias) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) atomicAdd(dbias + cc + k, sum[k]);
+    }
+  }
+}
+
 DwGeom make_geom(int B, int H, int W, int C, int k, int nhwc) {
   DwGeom g;
   g.B = B; g.H = H; g.W = W; g.C = C; g.k = k; g.nhwc = nhwc;
@@ -124,6 +254,15 @@ extern "C" int bevr_dwconv_fwd(const float* x, const float* w, const float* bias
                                int k, int nhwc, int flip, void* stream) {
   if (!x || !w || !y) return BEVR_E_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || k > 5 || (k & 1) == 0) return BEVR_E_SHAPE;
+  if (nhwc && (C & 3) == 0 && (k == 3 || k == 5) && bevr_aligned16(x) && bevr_aligned16(y) && (!bias || bevr_aligned16(bias))) {
+    const long nthr = (long)B * H * ((W + DW_XT - 1) / DW_XT) * (C >> 2);
+    const dim3 grid((unsigned)((nthr + 255) / 256));
+    if (k == 3)
+      hipLaunchKernelGGL(dwconv_fwd_nhwc4_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, B, H, W, C, x, w, bias, y, flip);
+    else
+      hipLaunchKernelGGL(dwconv_fwd_nhwc4_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, B, H, W, C, x, w, bias, y, flip);
+    return (int)hipGetLastError();
+  }
   const DwGeom g = make_geom(B, H, W, C, k, nhwc);
   const long n = (long)B * H * W * C;
   hipLaunchKernelGGL(dwconv_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, x, w, bias, y,
@@ -135,6 +274,14 @@ extern "C" int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, flo
                                  int nhwc, void* stream) {
   if (!x || !dy || !dw) return BEVR_E_NULL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || k < 1 || k > 5 || (k & 1) == 0) return BEVR_E_SHAPE;
+  const int c4n = C >> 2;
+  if (nhwc && (C & 3) == 0 && k == 3 && (c4n >= 64 || (c4n & (c4n - 1)) == 0) && bevr_aligned16(x) && bevr_aligned16(dy)) {
+    const int qpw = c4n < 64 ? c4n : 64;
+    const long nblk = (long)B * ((H + 3) / 4) * ((c4n + qpw - 1) / qpw);
+    hipLaunchKernelGGL(dwconv_bwd_w_nhwc4_kernel<3>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, B, H, W, C, x, dy,
+                       dw, dbias);
+    return (int)hipGetLastError();
+  }
   const DwGeom g = make_geom(B, H, W, C, k, nhwc);
   const long n_line = nhwc ? (long)B * H * C : (long)B * C * W;
   hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3((unsigned)((n_line + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, x, dy,

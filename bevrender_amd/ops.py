@@ -345,6 +345,7 @@ class _AttnCore(torch.autograd.Function):
             feat, spos = feat.contiguous(), spos.float().contiguous()
             N, C2 = spos.shape[1], 2 * feat.shape[-1]
             W_e = Wkv.detach().to(ed).contiguous()
+            vn2 = torch.zeros(1, device=Qp.device, dtype=torch.float32)   # largest squared V row norm (kv_project)
             b_f = None if bkv is None else bkv.detach().float().contiguous()
         else:
             kv = kv.float().contiguous()
@@ -377,7 +378,7 @@ class _AttnCore(torch.autograd.Function):
                 _lib.check(KERNEL_TIMER.run(
                     "bevr_kv_project", 0.0, L.bevr_kv_project, _ptr(feat), int(feat.dtype == torch.bfloat16),
                     C.c_void_p(spos.data_ptr() + sg.n0 * 8), N, _ptr(W_e), _ptr(b_f), nb, Hi, Wi, Cc, g.N, g.Np, g.heads, c,
-                    g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _stream(),
+                    g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _ptr(vn2) if need_bwd else None, _stream(),
                     nbytes=float(feat.numel() * feat.element_size() + 8 * nb * g.N + (4 if need_bwd else 3) * Ke.numel() * 2)),
                     "bevr_kv_project")
             else:
@@ -409,7 +410,7 @@ class _AttnCore(torch.autograd.Function):
         ctx.fused = fused
         if fused:
             ctx.n_seg_saved = len(saved)
-            saved += [feat, spos, Wkv] + ([bkv] if bkv is not None else [])
+            saved += [feat, spos, Wkv, vn2] + ([bkv] if bkv is not None else [])
             ctx.has_bias = bkv is not None
         ctx.save_for_backward(Qe, pair, O, LSE, *saved)
         return O
@@ -455,8 +456,12 @@ class _AttnCore(torch.autograd.Function):
         #             dO and delta as it loads them -- exact -- and ln2 / s when it stores);
         #   fp16 only: [2] kp with Pmax 2^kp <= 2^14 (softmax weights as fp16 operands), [3] c2 with
         #             Pmax bound 2^kp c2 <= 2^14 (logit gradients as fp16 operands), [4], [5] the inverses; s = 2^16 2^kp c2.
-        vmax = ctx.vmax if x3 else \
-            torch.stack([saved[6 * i + 1].float().norm(dim=-1).max() for i in range(len(ctx.segs))]).max()
+        if ctx.fused:      # from the packing kernel (squared, of the unrounded rows: + 1 % for the rounding to E)
+            vmax = src[3][0].sqrt() * 1.01
+        elif x3:
+            vmax = ctx.vmax
+        else:
+            vmax = torch.stack([saved[6 * i + 1].float().norm(dim=-1).max() for i in range(len(ctx.segs))]).max()
         bound = (dOr.norm(dim=-1).max() * vmax + delta.abs().max()).clamp_min(1e-30)
         pmax_log2 = (LSE[1].max() + 0.05).clamp(-60.0, 0.0)
         zero, one = torch.zeros((), device=dev), torch.ones((), device=dev)

@@ -665,8 +665,9 @@ def test_kv_project_equals_sample_gemm_pack(shape, feat_bf16, prec):
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     We = W.to(ed).contiguous()
+    vn2 = torch.zeros(1, device=DEV)
     rc = _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), C.c_void_p(pos.data_ptr() + n0 * 8), N, p(We), p(bias), Bp, Hi,
-                                    Wi, Cc, Ns, Np, h, c, prec, p(Kr), p(Vr), p(Kt), p(Vt), st)
+                                    Wi, Cc, Ns, Np, h, c, prec, p(Kr), p(Vr), p(Kt), p(Vt), p(vn2), st)
     assert rc == 0
     xs = ops._Sample.sample(feat, pos)[:, n0:]                              # float samples, the unfused kernel
     kv = (xs.to(ed).double() @ We.double().t() + bias.double()).float()     # products of E values, exact accumulation
@@ -680,16 +681,19 @@ def test_kv_project_equals_sample_gemm_pack(shape, feat_bf16, prec):
     # padded keys: zeros, no bias (transposed layout: whole 32-blocks past the last key; inside a block the order is permuted
     # and the comparison with _perm_t above covers it)
     assert (Kr[:, :, Ns:] == 0).all() and (Vt[..., 32 * ((Ns + 31) // 32):] == 0).all()
+    # the largest squared V row norm, for the backward's scale bound
+    want_n2 = Vw.float().pow(2).sum(-1).max().item()
+    assert abs(vn2.item() - want_n2) <= 0.02 * want_n2
     if c < 32:
         assert (Kr[..., c:] == 0).all() and (Vt[:, :, c:] == 0).all()       # padded head channels
     # no transposed K requested (forward-only call)
     Kr2, Vr2, Vt2 = mk(Bp, h, Np, 32), mk(Bp, h, Np, 32), mk(Bp, h, 32, Np)
     assert _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), C.c_void_p(pos.data_ptr() + n0 * 8), N, p(We), p(bias), Bp,
-                                      Hi, Wi, Cc, Ns, Np, h, c, prec, p(Kr2), p(Vr2), None, p(Vt2), st) == 0
+                                      Hi, Wi, Cc, Ns, Np, h, c, prec, p(Kr2), p(Vr2), None, p(Vt2), None, st) == 0
     assert torch.equal(Kr2, Kr) and torch.equal(Vt2, Vt)
     # argument contract: f32-layout modes are refused
     assert _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), p(pos), N, p(We), p(bias), Bp, Hi, Wi, Cc, Ns, Np, h, c,
-                                      _lib.PREC_F32, p(Kr), p(Vr), None, p(Vt), st) == -3
+                                      _lib.PREC_F32, p(Kr), p(Vr), None, p(Vt), None, st) == -3
 
 
 @pytest.mark.gpu

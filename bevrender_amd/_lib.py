@@ -28,7 +28,7 @@ SYMBOLS = [
     "bevr_attn_fwd", "bevr_attn_bwd_q",
     "bevr_attn_bwd_k", "bevr_attn_cell_fwd", "bevr_attn_cell_bwd_q", "bevr_attn_cell_bwd_k", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_sample_fwd_bf16", "bevr_sample_bwd_bf16", "bevr_project_bev_grid", "bevr_project_bev_grid_masked", "bevr_corr_fwd",
     "bevr_corr_bwd", "bevr_recall_rank", "bevr_dwconv_fwd", "bevr_dwconv_bwd_w", "bevr_affine_warp_fwd", "bevr_affine_warp_bwd",
-    "bevr_offset_head_fwd", "bevr_offset_head_bwd", "bevr_key_positions_fwd", "bevr_key_positions_bwd", "bevr_kv_project", "bevr_pack_kv", "bevr_unpack_dkv",
+    "bevr_offset_head_fwd", "bevr_offset_head_bwd", "bevr_key_positions_fwd", "bevr_key_positions_bwd", "bevr_kv_project", "bevr_layernorm_fwd", "bevr_layernorm_bwd", "bevr_pack_kv", "bevr_unpack_dkv",
 ]
 
 
@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
         L.bevr_affine_warp_bwd.argtypes = [fp, fp, fp] + [ip] * 4 + [vp]
         L.bevr_offset_head_fwd.argtypes = [fp] * 7 + [C.c_longlong] + [ip] * 4 + [C.c_float, vp]
         L.bevr_offset_head_bwd.argtypes = [fp] * 13 + [C.c_longlong] + [ip] * 4 + [C.c_float, vp]
+        L.bevr_layernorm_fwd.argtypes = [fp] * 6 + [C.c_longlong, ip, C.c_float, vp]
+        L.bevr_layernorm_bwd.argtypes = [fp] * 8 + [C.c_longlong, ip, vp]
         L.bevr_kv_project.argtypes = [vp, ip, fp, C.c_longlong, vp, fp] + [ip] * 9 + [vp] * 6
         L.bevr_key_positions_fwd.argtypes = [fp, fp, vp, fp] + [ip] * 8 + [C.c_float, C.c_float, vp]
         L.bevr_key_positions_bwd.argtypes = [fp, fp, vp, fp, fp] + [ip] * 8 + [C.c_float, C.c_float, vp]

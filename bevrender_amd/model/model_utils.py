@@ -44,8 +44,12 @@ class LayerNormProxy(nn.Module):
         self.norm = nn.LayerNorm(dim)
 
     def forward(self, x):
-        y = F.layer_norm(x.permute(0, 2, 3, 1), self.norm.normalized_shape, self.norm.weight, self.norm.bias,
-                         self.norm.eps)
+        xh = x.permute(0, 2, 3, 1)
+        if x.is_cuda and x.dtype == torch.float32 and self.norm.elementwise_affine:
+            from .. import ops
+            if ops.layer_norm_supported(xh.shape[-1]):          # HIP: csrc/layernorm.hip
+                return ops.layer_norm(xh, self.norm.weight, self.norm.bias, self.norm.eps).permute(0, 3, 1, 2)
+        y = F.layer_norm(xh, self.norm.normalized_shape, self.norm.weight, self.norm.bias, self.norm.eps)
         return y.permute(0, 3, 1, 2)
 
 

@@ -792,6 +792,48 @@ def offset_head(x: torch.Tensor, w0, b0, gamma: torch.Tensor, beta: torch.Tensor
     return _OffsetHead.apply(x, w0, b0, gamma, beta, W3, groups, eps)
 
 
+class _LayerNorm(torch.autograd.Function):
+    """csrc/layernorm.hip: LayerNorm over the last axis of contiguous (.., C) rows."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _require_gpu(x, gamma, beta)
+        x = x.float().contiguous()
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        gamma, beta = gamma.float().contiguous(), beta.float().contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        _lib.check(_lib.lib().bevr_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, Cc,
+                                                float(eps), _stream()), "bevr_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        Cc = x.shape[-1]
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+        db = torch.zeros_like(dg)
+        _lib.check(_lib.lib().bevr_layernorm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg),
+                                                _ptr(db), x.numel() // Cc, Cc, _stream()), "bevr_layernorm_bwd")
+        return dx, dg, db, None
+
+
+def layer_norm_supported(C: int) -> bool:
+    c4 = C // 4
+    return C % 4 == 0 and 0 < c4 <= 64 and (c4 & (c4 - 1)) == 0
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """LayerNorm over the last axis of a channels-last tensor (.., C): y = (x - mean) / sqrt(var + eps) * gamma + beta
+    (biased variance, as nn.LayerNorm).  Replaces F.layer_norm in LayerNormProxy (model/model_utils.py:37-49)."""
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
 class _KeyPositions(torch.autograd.Function):
     """csrc/keypos.hip: offset-head outputs -> key positions in the attention's key order (one launch), and the adjoint."""
 

@@ -23,6 +23,7 @@
  *   bevr_pack_kv/unpack_dkv model/SCA_deform_attn.py:312-321 (projection outputs -> per-head operand layouts)
  *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
  *   bevr_offset_head_fwd/bwd  model/SCA_deform_attn.py:56-77, model/TSA_deform_attn.py:54-68 (offset heads, fused)
+ *   bevr_layernorm_fwd/bwd  model/model_utils.py:37-49, model/encoder.py:275 (LayerNormProxy)
  *   bevr_kv_project         model/SCA_deform_attn.py:290-321, model/TSA_deform_attn.py:210-236 (sample + proj_k | proj_v + pack)
  *   bevr_key_positions_fwd/bwd  model/SCA_deform_attn.py:248-277, model/TSA_deform_attn.py:170-196 (row split, tanh range, + ref, key order)
  *   bevr_affine_warp_fwd/bwd  model/encoder.py:413-466 (project_history_bev_feat: torchvision F.affine, twice)
@@ -275,6 +276,17 @@ int bevr_pack_kv(const float* k, const float* v, long long ld, long long pstride
                  int c, int precision, void* Kr, void* Vr, void* Kt, void* Vt, void* stream);
 int bevr_unpack_dkv(const float* dK, const float* dV, float* dk, float* dv, long long ld, long long pstride, int n_prob,
                     int N, int Np, int heads, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm over the channel axis of channels-last rows, forward and backward (LayerNormProxy,
+ * model/model_utils.py:37-49; the norm an EncoderLayer shares between its four uses, model/encoder.py:275).
+ *   x, y, dy, dx [rows][C] float;  gamma, beta [C];  mean, rstd [rows] (written by the forward, read by the backward)
+ *   C % 4 == 0, C / 4 a power of two <= 64.   backward: dx written, dgamma / dbeta [C] ACCUMULATED (caller zeroes).
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       long long rows, int C, float eps, void* stream);
+int bevr_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
+                       float* dx, float* dgamma, float* dbeta, long long rows, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K | V operands straight from the feature map (16-bit operand modes): bilinear sampling at `pos` -> proj_k | proj_v

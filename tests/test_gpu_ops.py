@@ -732,3 +732,26 @@ def test_attention_core_with_fused_kv_source_matches_the_unfused_chain(prec):
         e = rel_err(a.cpu(), b.cpu())
         print(f"[fused kv prec={prec}] grad {n} rel diff {e:.2e}")
         assert e < 2.5 * lim, f"grad {n}: {e:.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 7, 9, 64), (1, 40, 40, 64), (3, 5, 5, 8), (1, 13, 1, 256), (2, 3, 4, 4), (5, 1, 1, 128)])
+def test_layer_norm_matches_torch(shape):
+    """csrc/layernorm.hip against F.layer_norm in float64: forward, input gradient, d(gamma), d(beta); row counts that
+    do not fill the last lane group / workgroup."""
+    Cc = shape[-1]
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=gen) * 2.0 + 0.5
+    gamma, beta = torch.randn(Cc, generator=gen), torch.randn(Cc, generator=gen)
+    cot = torch.randn(*shape, generator=gen)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    want = F.layer_norm(xr, (Cc,), gr, br, 1e-5)
+    want.backward(cot.double())
+    xg, gg, bg = (t.clone().to(DEV).requires_grad_(True) for t in (x, gamma, beta))
+    got = ops.layer_norm(xg, gg, bg, 1e-5)
+    got.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-5)
+    assert rel_err(xg.grad.cpu().double(), xr.grad) < 2e-5
+    assert rel_err(gg.grad.cpu().double(), gr.grad) < 2e-5
+    assert rel_err(bg.grad.cpu().double(), br.grad) < 2e-5

@@ -126,11 +126,30 @@ __global__ __launch_bounds__(twc<PREC>(), is16(PREC) ? 3 : 2) void attn_cell_bwd
   const StepBox sb = kbox[wave_live ? k0 / 32 : 0];     // the tile's box (scalar)
   const bool tile_live = wave_live && sb.amax >= sb.amin;
   const bool any_dead = __any(dead);
-  if constexpr (SLOW) {   // anything for this workgroup?  (per wave: a scan over the BEV columns; then a workgroup-wide OR)
-    bool mine = false;
+  // SLOW: the BEV columns in which SOME wave's tile does not fit a chunk, listed in ascending order (deterministic);
+  // the sweep below visits only those (a workgroup with one slow (tile, column) pair used to sweep all S columns)
+  __shared__ unsigned char col_flag[SLOW ? 1024 : 1];
+  __shared__ short col_list[SLOW ? 1024 : 1];
+  __shared__ int col_count;
+  if constexpr (SLOW) {
+    for (int jj = tid; jj < d.S; jj += TWC) col_flag[jj] = 0;
+    __syncthreads();
     if (tile_live)
-      for (int jj = 0; jj < d.S; ++jj) mine = mine || !make_celltile(sb, (float)jj * rx).fast;
-    if (!__syncthreads_or(mine)) return;
+      for (int jj = lane; jj < d.S; jj += 64)
+        if (!make_celltile(sb, (float)jj * rx).fast) col_flag[jj] = 1;   // benign race: every writer stores 1
+    __syncthreads();
+    if (tid < 64) {
+      int cnt = 0;
+      for (int b0 = 0; b0 < d.S; b0 += 64) {
+        const bool f = b0 + lane < d.S && col_flag[b0 + lane];
+        const unsigned long long mask = __ballot(f);
+        if (f) col_list[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (short)(b0 + lane);
+        cnt += __popcll(mask);
+      }
+      if (lane == 0) col_count = cnt;
+    }
+    __syncthreads();
+    if (col_count == 0) return;
   }
   Frag<PREC> kf, vf;
   kf.load(Kh + (size_t)key * 32 * EB, hi);
@@ -181,16 +200,20 @@ __global__ __launch_bounds__(twc<PREC>(), is16(PREC) ? 3 : 2) void attn_cell_bwd
           Qt + ((size_t)(qb * d.heads + hd) * 32) * Mp * EB, dOt + ((size_t)ph * 32) * Mp * EB,
           LSE + (size_t)ph * Mp, delta + (size_t)ph * Mp, Mp, kp16);
   // tile it = (BEV column j = it / n_rb, row block rb = it % n_rb) is the 32 packed queries [32 it, 32 it + 32)
-  const int n_it = d.S * n_rb;
-  qs.load(tid, 0);
+  const int n_col = SLOW ? col_count : d.S;
+  const int n_it = n_col * n_rb;
+  // iteration -> (BEV column, row block) -> first packed query of the tile
+  auto col_of = [&](int it_) { const int cj = it_ / n_rb; return SLOW ? (int)col_list[cj] : cj; };
+  auto mq_of = [&](int it_) { return (size_t)(col_of(it_) * n_rb + it_ % n_rb) * 32; };
+  qs.load(tid, mq_of(0));
   qs.store(tid, smem);
   __syncthreads();
 
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
     const char* base = smem + buf * L::BUF;
-    if (it + 1 < n_it) qs.load(tid, (size_t)(it + 1) * 32);
-    const int j = it / n_rb, rb = it - j * n_rb;
+    if (it + 1 < n_it) qs.load(tid, mq_of(it + 1));
+    const int j = col_of(it), rb = it % n_rb;
 
     if (rb == 0) {
       jr = (float)j * rx;
@@ -382,6 +405,7 @@ extern "C" int bevr_attn_cell_bwd_k(const bevr_attn_desc* d, const void* Q, cons
                                     float* dV, float* dkey_a, float* dkey_b, void* stream) {
   int rc = bevr_check_desc(d);
   if (rc) return rc;
+  if (d->S > 1024) return BEVR_E_SHAPE;   // the slow pass lists its BEV columns in LDS (1024 entries)
   if (!Q || !Qt || !K || !V || !key_ws || !table_pair || !dO || !dOt || !LSE || !delta || !dK || !dV || !dkey_a ||
       !dkey_b || (d->precision == BEVR_PREC_F16 && !grad_scale))
     return BEVR_E_NULL;

@@ -10,12 +10,17 @@ the reference itself:
   * the batch size is read from the tensors (data-parallel shards), not from the constructor.
 All views are batched into one sampling launch and one attention launch.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from .. import ops, resolve_precision
 from .model_utils import LayerNormProxy, trunc_normal_
+
+# keys per view and call that move from the cell segment's sparse tail to the region kernels (ops.cell_order)
+CELL_TAIL = int(os.environ.get("BEVR_CELL_TAIL", "128"))
 
 
 class SCADeformableAttention(nn.Module):
@@ -131,10 +136,12 @@ class SCADeformableAttention(nn.Module):
         if cell_split is not None and cell_split < N and g == 1:
             # groups > 1: a key is one row of K built from all groups' samples, so the groups cannot be ordered
             # independently; the split is simply not used then
+            n_tail = min(CELL_TAIL, max(0, N - cell_split - 1024))
             with torch.no_grad():
                 a, b = ops.key_coords(pos[:, cell_split:], S, self.rpe_table.shape[-1], N - cell_split)
-                dyn = ops.cell_order(a, b)
+                dyn = ops.cell_order(a, b, n_tail)
             pos = torch.cat((pos[:, :cell_split], pos[:, cell_split:].gather(1, dyn[..., None].expand(-1, -1, 2))), 1)
+            cell_split = cell_split + n_tail      # the keys of the sparsest cells join the region segment (ops.cell_order)
         else:
             cell_split = None
         # proj_k and proj_v as ONE GEMM over the sampled features (same arithmetic per output column; the features are

@@ -299,18 +299,38 @@ def _attn_flops(geom, n_matmul, n_keys=None):
     return 2.0 * HEAD_DIM * geom.n_prob * geom.heads * (geom.S * geom.S) * n * n_matmul
 
 
-def cell_order(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def cell_order(a: torch.Tensor, b: torch.Tensor, n_tail: int = 0) -> torch.Tensor:
     """The order that makes a key segment CELL-SORTED (csrc/attn_cell.h): per problem, keys sorted by rpe-table cell
     (floor(a), floor(b)), rows ascending, columns boustrophedon (consecutive cells are neighbours).  a, b (P, N) table
     coordinates -> (P, N) long.  Softmax attention is invariant to the order of its keys: the order only decides how
-    many 32-key tiles of the segment fit one table chunk."""
+    many 32-key tiles of the segment fit one table chunk.
+
+    n_tail > 0: the n_tail keys that sit in the LEAST POPULATED cells come first (in cell order among themselves), the
+    cell-sorted rest after them.  The caller hands those first n_tail keys to the region kernels: in the sparse tail of
+    the offset distribution a 32-key tile spans more than one 4 x 4 chunk and takes the cell kernels' slow pass (~200x
+    a fast tile); at the benchmark rig moving 128 keys per view removes 4 of 5 slow tiles
+    (tools/analysis/slow_tiles.py).  No host sync: populations are run lengths of the sorted cell ids."""
     A = torch.floor(a).to(torch.int64)
     Bc = torch.floor(b).to(torch.int64)
     A = A - A.amin(1, keepdim=True)
     Bc = Bc - Bc.amin(1, keepdim=True)
     nB = Bc.amax(1, keepdim=True) + 1
     snake = torch.where(A % 2 == 0, Bc, nB - 1 - Bc)
-    return (A * nB + snake).argsort(1)
+    cid = A * nB + snake
+    order = cid.argsort(1)
+    if n_tail <= 0:
+        return order
+    P, N = cid.shape
+    s = cid.gather(1, order)
+    idx = torch.arange(N, device=cid.device).expand(P, N)
+    edge = s[:, 1:] != s[:, :-1]
+    t = torch.ones(P, 1, dtype=torch.bool, device=cid.device)
+    first = torch.where(torch.cat((t, edge), 1), idx, torch.zeros_like(idx)).cummax(1).values           # run start
+    last = torch.where(torch.cat((edge, t), 1), idx, torch.full_like(idx, N)).flip(1).cummin(1).values.flip(1)  # run end
+    pop = last - first + 1                                     # population of each key's cell, in cell order
+    tail = pop.argsort(dim=1, stable=True)[:, :n_tail]             # positions (in cell order) of the sparsest cells' keys
+    flag = torch.ones(P, N, dtype=torch.int64, device=cid.device).scatter_(1, tail, 0)
+    return order.gather(1, flag.argsort(dim=1, stable=True))       # tail first, the rest after it, both in cell order
 
 
 @dataclass

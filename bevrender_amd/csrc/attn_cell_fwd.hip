@@ -415,6 +415,94 @@ __global__ __launch_bounds__(MAXT) void attn_cell_fwd_kernel(
     }
   };
 
+  // f32-layout modes (fragments twice as wide): the same, ONE tile at a time -- the joint body needs 214 registers there,
+  // this one 156 (512-thread instantiation, no spills): 48 -> 44 ms on tools/prof_cell.py in the split-bf16 mode.  At the
+  // 1024-thread bound (128 registers, two workgroups per CU) it spills 88 B per lane and is slower (48.6 ms).  (In the 16-bit modes this second body next to the joint
+  // one is what spilled; here it is the only one: a generic lambda is only instantiated where it is called.)
+  auto tile1 = [&](auto masked_tag, auto t_tag, const char* base, int step, int x0, int a0) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr int T = decltype(t_tag)::value;
+    CellFrag<PREC>& tf = T ? tf1 : tf0;
+    int& tag_x = T ? tag_x1 : tag_x0;
+    int& tag_a = T ? tag_a1 : tag_a0;
+    if (x0 != tag_x || a0 != tag_a) {   // uniform: new chunk origin
+      tf = cell_table<PREC>(tbl, d, x0, a0 + i0 + lq, hi);
+      tag_x = x0;
+      tag_a = a0;
+    }
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      {
+        Frag<PREC> kf, qf;
+        kf.load(base + (T * 32 + lq) * L::K_STRIDE, hi);
+        load_q(qf);
+        s = mma_frag(kf, qf, s);   // S^T[key][query]
+      }
+      {
+        CellFrag<PREC> wf;
+        load_w(wf, base + L::OFF_W + (T * 64 + lane) * L::WL);
+        s = mma_cell(wf, tf, s);   // + bias^T[key][query]
+      }
+      if constexpr (MASKED) {   // padded keys: no weight
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = (step * KT + T * 32 + crow(r, hi) >= d.N) ? BEVR_NEG_BIG : s[r];
+      }
+      if (first || attempt == 1) {   // exact maximum of the tile: sets / moves the reference before the weights are formed
+        float tm = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tm = fmaxf(tm, s[r]);
+        tm = fmaxf(tm, __shfl_xor(tm, 32)) - shift16<PREC>();
+        const float mn = first ? tm : fmaxf(m, tm);
+        const float al = first ? 0.f : fast_exp2(m - mn);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= al;
+        l *= al;
+        m = mn;
+        first = false;
+      }
+      const f32x2 nm = {-m, -m};
+      f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sh = f32x2{s[r], s[r + 1]} + nm;
+        const f32x2 pp = {fast_exp2(sh[0]), fast_exp2(sh[1])};
+        s[r] = pp[0];
+        s[r + 1] = pp[1];
+        ls2 += pp;
+      }
+      const float ts = ls2[0] + ls2[1];
+      if (attempt == 0 && __any(!(ts <= mass_redo<PREC>()))) continue;   // overflowed against the old reference: redo exactly
+      l += ts;
+      {
+        Frag<PREC> vf;
+        load_perm(vf, base + L::OFF_V + lq * L::V_STRIDE + T * 32 * EB, hi);
+        o = mma_acc_b(vf, s, o);
+      }
+      if (__any(ts > mass_thr<PREC>())) {   // wave-uniform, rare: keep every committed weight <= mass_thr of the reference
+        const float tb = ts + __shfl_xor(ts, 32);
+        const float up = fmaxf(ceilf(__log2f(tb)) - shift16<PREC>(), 0.f);
+        const float al = fast_exp2(-up);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= al;
+        l *= al;
+        m += up;
+      }
+      break;
+    }
+  };
+  // both tiles of a step
+  auto tiles = [&](auto masked_tag, const char* base, int step, int ok0, int ok1, int x00, int a00, int x01, int a01) {
+    if constexpr (is16(PREC)) {
+      tile2(masked_tag, base, step, ok0, ok1, x00, a00, x01, a01);
+    } else {
+      if (ok0) tile1(masked_tag, std::integral_constant<int, 0>{}, base, step, x00, a00);
+      if (ok1) tile1(masked_tag, std::integral_constant<int, 1>{}, base, step, x01, a01);
+    }
+  };
+
   // ---- staging helpers -------------------------------------------------------------------------------------
   u32x4 st[L::NST];
   const char* st_src[L::NST];
@@ -520,7 +608,7 @@ __global__ __launch_bounds__(MAXT) void attn_cell_fwd_kernel(
       const int ok0 = __builtin_amdgcn_readfirstlane((int)(cw0[0] & cw0[1])), ok1 = __builtin_amdgcn_readfirstlane((int)(cw1[0] & cw1[1]));
       const int x00 = __builtin_amdgcn_readfirstlane((int)cw0[2]), a00 = __builtin_amdgcn_readfirstlane((int)cw0[3]);
       const int x01 = __builtin_amdgcn_readfirstlane((int)cw1[2]), a01 = __builtin_amdgcn_readfirstlane((int)cw1[3]);
-      if (ok0 | ok1) tile2(std::false_type{}, base, step, ok0, ok1, x00, a00, x01, a01);
+      if (ok0 | ok1) tiles(std::false_type{}, base, step, ok0, ok1, x00, a00, x01, a01);
 
       if (more) {
 #if defined(BEVR_VARIANT) && BEVR_VARIANT == 2   // timing probe only (stale weights): what the builder wave costs the step
@@ -543,7 +631,7 @@ __global__ __launch_bounds__(MAXT) void attn_cell_fwd_kernel(
       const u32x4 cw1 = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + 16);
       const int ok0 = __builtin_amdgcn_readfirstlane((int)(cw0[0] & cw0[1])), ok1 = __builtin_amdgcn_readfirstlane((int)(cw1[0] & cw1[1]));
       if (ok0 | ok1)
-        tile2(std::true_type{}, base, n_main, ok0, ok1, __builtin_amdgcn_readfirstlane((int)cw0[2]),
+        tiles(std::true_type{}, base, n_main, ok0, ok1, __builtin_amdgcn_readfirstlane((int)cw0[2]),
               __builtin_amdgcn_readfirstlane((int)cw0[3]), __builtin_amdgcn_readfirstlane((int)cw1[2]),
               __builtin_amdgcn_readfirstlane((int)cw1[3]));
     }

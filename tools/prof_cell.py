@@ -21,7 +21,7 @@ q = torch.randn(B, C, S, S, device=dev, generator=gen, requires_grad=True)
 k = torch.randn(P, N, C, device=dev, generator=gen, requires_grad=True)
 v = torch.randn(P, N, C, device=dev, generator=gen, requires_grad=True)
 table = (torch.randn(h, 2 * S - 1, Wt, device=dev, generator=gen) * 0.3).requires_grad_(True)
-prec = _lib.PREC_BF16 if os.environ.get("PREC", "bf16") == "bf16" else _lib.PREC_F32
+prec = {"bf16": _lib.PREC_BF16, "f16": _lib.PREC_F16, "bf16x3": _lib.PREC_BF16X3, "f32": _lib.PREC_F32}[os.environ.get("PREC", "bf16")]
 for it in range(int(os.environ.get("ITERS", "3"))):
     ops.KERNEL_TIMER.start()
     out = ops.attention_core(q, k, v, pos, table, heads=h, groups=1, views=V, precision=prec, cell_split=0)

@@ -94,9 +94,13 @@ class LiftBlock(nn.Module):
             x, _ = layer(x, feats, prev_bev, None, vt, None, False)
         return x
 
-    def forward(self, feats_hist, feats_cur, map_emb):
+    def forward(self, feats_hist, feats_cur, map_emb, n_hist=1):
+        """n_hist no-grad history frames chained through TSA's prev_bev (the reference's recurrence over frames), then
+        the current frame forward + backward.  The default T = 2 is one history frame."""
         with torch.no_grad():
-            prev = self.encode(feats_hist, None)
+            prev = None
+            for _ in range(n_hist):
+                prev = self.encode(feats_hist, prev)
         bev = self.encode(feats_cur, prev)
         emb = bev.flatten(1)
         corr = self.loss.get_loss(emb, map_emb) + self.lift.get_loss(emb, map_emb)   # config 3: contrastive + lifted
@@ -247,6 +251,8 @@ def main():
                     help="also time this many steps in the fp32-tolerance mode (split-bf16 products, bf16x3) and in the "
                          "exact-f32 MFMA mode (rank 0, N=1; 0 = skip)")
     ap.add_argument("--bev", type=int, default=200, help="BEV side (200 = BASELINE config; smaller for debugging)")
+    ap.add_argument("--frames", type=int, default=2, help="temporal frames T: T - 1 no-grad history frames + the current one")
+    ap.add_argument("--img", default="704x256", help="camera image WxH (features are 1/4 of it); config 5: 1408x512")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "f16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -277,7 +283,7 @@ def main():
 
     from bevrender_amd import _lib, ops
     S, C, heads, D, V, L, B = args.bev, 64, 2, 5, 6, 2, args.batch
-    img_w, img_h = 704, 256
+    img_w, img_h = (int(v) for v in args.img.lower().split("x"))
     Hi, Wi = img_h // 4, img_w // 4
     torch.manual_seed(15213 + rank)
     model = LiftBlock(S, C, heads, D, V, L, img_w, img_h, args.precision, dev).to(dev)
@@ -294,7 +300,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = net(feats[0], feats[1], map_emb)
+        loss = net(feats[0], feats[1], map_emb, args.frames - 1)
         loss.backward()
         opt.step()
         return loss
@@ -399,9 +405,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if rehearsal else ""),
-            "config": {"workload": f"cfg{3 if B == 8 else 2}{'' if B == 8 else '+corr'}: 6-cam 256x704 features (64x64x176), "
-                                   f"{S}x{S} BEV, C=64 h=2 D=5, L=2 encoder layers (TSA+SCA), T=2 (1 no-grad history frame "
-                                   f"+ 1 fwd+bwd), correlation head with contrastive + lifted-structure losses, AdamW; "
+            "config": {"workload": (f"cfg{3 if B == 8 else 2}{'' if B == 8 else '+corr'}"
+                                    if (S, args.frames, args.img) == (200, 2, "704x256") else "non-default shape") +
+                                   f": 6-cam {img_h}x{img_w} features (64x{Hi}x{Wi}), "
+                                   f"{S}x{S} BEV, C=64 h=2 D=5, L=2 encoder layers (TSA+SCA), T={args.frames} "
+                                   f"({args.frames - 1} no-grad history frame(s) + 1 fwd+bwd), correlation head with "
+                                   f"contrastive + lifted-structure losses, AdamW; "
                                    f"batch {B} per GPU; backbone/render CNN excluded",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             "roofline": roof, "roofline_hbm": roof_hbm, "roofline_lds": roof_lds,
@@ -419,7 +428,7 @@ def main():
 
                 def step32():
                     o32.zero_grad(set_to_none=True)
-                    m32(feats[0], feats[1], map_emb).backward()
+                    m32(feats[0], feats[1], map_emb, args.frames - 1).backward()
                     o32.step()
                 step32()
                 torch.cuda.synchronize()

@@ -363,7 +363,9 @@ __global__ __launch_bounds__(TF, is16(PREC) ? 4 : 2) void attn_fwd_kernel(
         // the two lane halves hold the same queries (different keys): agree on the maximum only when it is needed
         tm = fmaxf(tm, __shfl_xor(tm, 32)) - ref_shift<PREC>();
         const float up = first ? tm : fmaxf(tm, 0.f);   // the max only moves up, except when it is first set
-        const float al = fast_exp2(-up);
+        // first tile: o and l are still zero and exp2(-up) may be +inf (all logits below -127: 0 * inf would be NaN;
+        // found by the config-5 run, where the history BEV grows over 6 frames)
+        const float al = first ? 0.f : fast_exp2(-up);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[r] *= al; s[r] -= up; }
         l *= al;

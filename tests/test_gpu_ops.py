@@ -755,3 +755,29 @@ def test_layer_norm_matches_torch(shape):
     assert rel_err(xg.grad.cpu().double(), xr.grad) < 2e-5
     assert rel_err(gg.grad.cpu().double(), gr.grad) < 2e-5
     assert rel_err(bg.grad.cpu().double(), br.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sign", [-1.0, 1.0])
+@pytest.mark.parametrize("prec", [_lib.PREC_F32, _lib.PREC_BF16X3, _lib.PREC_BF16, _lib.PREC_F16])
+def test_attention_with_every_logit_far_from_zero(prec, sign):
+    """Softmax is shift invariant, the kernels' first softmax reference must be too: every logit of every row near
+    -170 (-245 in the kernels' log2 units: 2^245 overflows float) or near +170.  Found by the config-5 run (6 temporal
+    frames: the history BEV grows, and with it K): the region forward scaled its still-zero accumulators by
+    exp2(-first tile max) = inf and returned NaN rows.  Region kernels, cell kernels and the two-segment chain."""
+    B, V, C, h, S, D, N = 1, 2, 64, 2, 12, 2, 200
+    gen = torch.Generator().manual_seed(3)
+    query = 2.0 + 0.1 * torch.randn(B, C, S, S, generator=gen)
+    k = sign * (15.0 + 0.1 * torch.randn(B * V, N, C, generator=gen))
+    v = torch.randn(B * V, N, C, generator=gen)
+    pos = torch.rand(B * V, N, 2, generator=gen) * 1.6 - 0.8
+    table = torch.randn(h, 2 * S - 1, 2 * S * D - 1, generator=gen) * 0.3
+    ins_cpu = [t.clone().double() for t in (query, k, v, pos, table)]
+    want = _oracle_core(*ins_cpu, h, 1, V)
+    lim = {_lib.PREC_F32: 2e-4, _lib.PREC_BF16X3: 2e-4, _lib.PREC_BF16: 6e-2, _lib.PREC_F16: 1e-2}[prec]
+    for split in (None, 0, N // 2):
+        got = ops.attention_core(*[t.to(DEV) for t in (query, k, v, pos, table)], heads=h, groups=1, views=V,
+                                 precision=prec, cell_split=split)
+        assert torch.isfinite(got).all(), f"split {split}: non-finite rows"
+        e = rel_err(got.cpu().double(), want)
+        assert e < lim, f"split {split}: rel err {e:.3e}"

@@ -772,12 +772,20 @@ def test_attention_with_every_logit_far_from_zero(prec, sign):
     v = torch.randn(B * V, N, C, generator=gen)
     pos = torch.rand(B * V, N, 2, generator=gen) * 1.6 - 0.8
     table = torch.randn(h, 2 * S - 1, 2 * S * D - 1, generator=gen) * 0.3
-    ins_cpu = [t.clone().double() for t in (query, k, v, pos, table)]
+    ins_cpu = [t.clone().double().requires_grad_(True) for t in (query, k, v, pos, table)]
     want = _oracle_core(*ins_cpu, h, 1, V)
+    cot = torch.randn(want.shape, generator=gen)
+    want.backward(cot.double())
     lim = {_lib.PREC_F32: 2e-4, _lib.PREC_BF16X3: 2e-4, _lib.PREC_BF16: 6e-2, _lib.PREC_F16: 1e-2}[prec]
     for split in (None, 0, N // 2):
-        got = ops.attention_core(*[t.to(DEV) for t in (query, k, v, pos, table)], heads=h, groups=1, views=V,
-                                 precision=prec, cell_split=split)
+        ins = [t.clone().to(DEV).requires_grad_(True) for t in (query, k, v, pos, table)]
+        got = ops.attention_core(*ins, heads=h, groups=1, views=V, precision=prec, cell_split=split)
         assert torch.isfinite(got).all(), f"split {split}: non-finite rows"
-        e = rel_err(got.cpu().double(), want)
+        e = rel_err(got.detach().cpu().double(), want.detach())
         assert e < lim, f"split {split}: rel err {e:.3e}"
+        got.backward(cot.to(DEV))
+        for n, a_, b_ in zip(("query", "k", "v", "table"), ins[:3] + ins[4:], ins_cpu[:3] + ins_cpu[4:]):
+            assert torch.isfinite(a_.grad).all(), f"split {split}: grad {n} non-finite"
+            eg = rel_err(a_.grad.cpu().double(), b_.grad)
+            # logits of magnitude 245 carry 245 x the float rounding of logits of magnitude 1, and dQ multiplies by |K| = 15
+            assert eg < 10 * lim, f"split {split}: grad {n} rel err {eg:.3e}"

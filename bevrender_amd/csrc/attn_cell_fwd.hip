@@ -109,7 +109,11 @@ __global__ __launch_bounds__(MAXT) void attn_cell_fwd_kernel(
   const int tid = threadIdx.x, nt = blockDim.x, n_wave = nt >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lq = lane & 31, hi = lane >> 5;
   const int Mp = d.S * d.Sp;
-  const int i0 = wave * 32;
+  // fast pass: the LAST wave is the workgroup's PRODUCER -- it stages the next step's keys and builds their weight
+  // tiles while the other waves (one per 32-row block) run the tiles; it owns no BEV rows (its row indices alias row
+  // block 0 so that the prologue below stays in range; it leaves before the epilogue)
+  const bool producer = !SLOW && wave == n_wave - 1;
+  const int i0 = (producer ? 0 : wave) * 32;
 
   const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB;
   const char* Kh = K + ((size_t)ph * d.Np) * 32 * EB;
@@ -503,19 +507,7 @@ __global__ __launch_bounds__(MAXT) void attn_cell_fwd_kernel(
     }
   };
 
-  // ---- staging helpers -------------------------------------------------------------------------------------
-  u32x4 st[L::NST];
-  const char* st_src[L::NST];
-  int st_inc[L::NST], st_dst[L::NST];
-#pragma unroll
-  for (int k = 0; k < L::NST; ++k) {
-    const int g = tid + k * nt;
-    // threads beyond the chunk count re-read chunk 0 into a dummy slot: loads and stores stay unconditional (a load
-    // under a branch feeding a loop-carried register is waited for on the spot)
-    chunk_map<PREC>(g < L::NCH ? g : 0, Kh, Vh, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
-    if (g >= L::NCH) st_dst[k] = L::OFF_DUMMY;
-  }
-  // copy a whole step through (small workgroups: the chunks beyond the registers' share; the slow pass: everything)
+  // copy a whole step through (the slow pass: every thread takes its share of the chunks)
   auto stage_direct = [&](char* base, int step, int g0) {
     for (int g = g0; g < L::NCH; g += nt) {
       const char* src;
@@ -539,90 +531,78 @@ __global__ __launch_bounds__(MAXT) void attn_cell_fwd_kernel(
     }
   } else {
     // ---- fast pass: pipelined over the steps --------------------------------------------------------------------
-    // weights and geometry of tile t of a step, by this wave (lane & 31 = key), into buffer `buf`
-    auto build_w = [&](int buf, int step, int t, const KeyW& kw, const StepBox& sb) {
-      const CellTile ct = make_celltile(sb, jrx);
-      float tcol, trow;
-      cell_coords(kw, jrx, ct.x0, step * KT + t * 32 + lq >= d.N, tcol, trow);
-      const CellFrag<PREC> w = cell_weights<PREC>(tcol, trow, hi);
-      char* bb = smem + buf * L::BUF;
-      char* dst = bb + L::OFF_W + (t * 64 + lane) * L::WL;
-      if constexpr (is16(PREC)) {
-        *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, w.v);
-      } else {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
-        *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
-      }
-      if (lane == 0) *reinterpret_cast<CellTile*>(bb + L::OFF_CT + t * 16) = ct;
-    };
-    auto load_kw = [&](int step, int t) {
-      return *reinterpret_cast<const KeyW*>(kws + ((size_t)step * KT + t * 32 + lq) * sizeof(KeyW));
-    };
-    // which wave builds tile t of a step: rotates, so that the extra work is spread evenly
-    auto builder_of = [&](int step, int t) { return (2 * step + t) % n_wave; };
-
-#pragma unroll
-    for (int k = 0; k < L::NST; ++k)
-      *reinterpret_cast<u32x4*>(smem + st_dst[k]) = gload16(st_src[k]);
-    stage_direct(smem, 0, tid + L::NST * nt);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (builder_of(0, t) == wave) build_w(0, 0, t, load_kw(0, t), kbox[t]);
-    __syncthreads();
-
-    StepBox sb_nxt[2] = {kbox[2 * min(1, n_step - 1)], kbox[2 * min(1, n_step - 1) + 1]};
     // a last step with padded keys is peeled off behind the loop (its masked tile body inside the loop cost every tile
     // registers or hoisted compares)
     const int n_main = d.N < d.Np ? n_step - 1 : n_step;
-    for (int step = 0; step < n_main; ++step) {
-      const int buf = step & 1;
-      const char* base = smem + buf * L::BUF;
-      const bool more = step + 1 < n_step;
-      if (more) {
+    if (producer) {
+      // ---- the producer wave: global -> registers -> LDS one step ahead, and the weight tiles / geometry of the step.
+      // Until round 3's last day every wave carried a share of the staging (8 registers, 2 loads, 2 LDS stores per
+      // step) and a rotating builder wave the weights: the builder arrived last at every barrier (probe: -9 %).
+      constexpr int NSTP = (L::NCH + 63) / 64;        // 16-byte chunks per lane and step
+      u32x4 st[NSTP];
+      const char* st_src[NSTP];
+      int st_inc[NSTP], st_dst[NSTP];
 #pragma unroll
-        for (int k = 0; k < L::NST; ++k) {
-#if defined(BEVR_VARIANT) && BEVR_VARIANT == 4   // timing probe: every step re-reads the first steps' (cache-hot) data
-          st_src[k] += (step < 8 ? st_inc[k] : 0);
-#else
-          st_src[k] += st_inc[k];
-#endif
-          st[k] = gload16(st_src[k]);
-        }
+      for (int k = 0; k < NSTP; ++k) {
+        const int g = lane + 64 * k;
+        // lanes beyond the chunk count re-read chunk 0 into a dummy slot: loads and stores stay unconditional
+        chunk_map<PREC>(g < L::NCH ? g : 0, Kh, Vh, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
+        if (g >= L::NCH) st_dst[k] = L::OFF_DUMMY;
       }
-      // the next step's key record for the tile this wave builds: loaded unconditionally (a load under a branch is
-      // waited for at the end of the branch, with every staging load in front of it: the builder wave then sat out a
-      // full memory latency per step and the workgroup waited for it at the barrier), consumed after the tiles.
-      // A wave builds at most one tile of a step (two only when it is the workgroup's only wave).
-      const int nstep_c = min(step + 1, n_step - 1);
-      const int tb = builder_of(step + 1, 1) == wave ? 1 : 0;
-      const bool bld = more && builder_of(step + 1, tb) == wave;
-      const KeyW kwn = load_kw(nstep_c, tb);
-      const StepBox sbb = sb_nxt[tb];
-      const StepBox sbo = sb_nxt[1 - tb];
-      sb_nxt[0] = kbox[2 * min(step + 2, n_step - 1)];
-      sb_nxt[1] = kbox[2 * min(step + 2, n_step - 1) + 1];
-
-      // the tiles' geometry, computed once by the builder: one broadcast read each instead of ~40 instructions per wave
+      // weights and geometry of tile t of a step (lane & 31 = key), into buffer `buf`
+      auto build_w = [&](int buf, int step, int t, const KeyW& kw, const StepBox& sb) {
+        const CellTile ct = make_celltile(sb, jrx);
+        float tcol, trow;
+        cell_coords(kw, jrx, ct.x0, step * KT + t * 32 + lq >= d.N, tcol, trow);
+        const CellFrag<PREC> w = cell_weights<PREC>(tcol, trow, hi);
+        char* bb = smem + buf * L::BUF;
+        char* dst = bb + L::OFF_W + (t * 64 + lane) * L::WL;
+        if constexpr (is16(PREC)) {
+          *reinterpret_cast<u32x4*>(dst) = __builtin_bit_cast(u32x4, w.v);
+        } else {
+          *reinterpret_cast<f32x4*>(dst) = f32x4{w.v[0], w.v[1], w.v[2], w.v[3]};
+          *reinterpret_cast<f32x4*>(dst + 16) = f32x4{w.v[4], w.v[5], w.v[6], w.v[7]};
+        }
+        if (lane == 0) *reinterpret_cast<CellTile*>(bb + L::OFF_CT + t * 16) = ct;
+      };
+      auto load_kw = [&](int step, int t) {
+        return *reinterpret_cast<const KeyW*>(kws + ((size_t)step * KT + t * 32 + lq) * sizeof(KeyW));
+      };
+#pragma unroll
+      for (int k = 0; k < NSTP; ++k) *reinterpret_cast<u32x4*>(smem + st_dst[k]) = gload16(st_src[k]);
+      build_w(0, 0, 0, load_kw(0, 0), kbox[0]);
+      build_w(0, 0, 1, load_kw(0, 1), kbox[1]);
+      __syncthreads();
+      for (int step = 0; step < n_main; ++step) {
+        if (step + 1 < n_step) {
+#pragma unroll
+          for (int k = 0; k < NSTP; ++k) {
+            st_src[k] += st_inc[k];
+            st[k] = gload16(st_src[k]);
+          }
+          const KeyW kw0 = load_kw(step + 1, 0), kw1 = load_kw(step + 1, 1);
+          const int nbuf = (step + 1) & 1;
+          build_w(nbuf, step + 1, 0, kw0, kbox[2 * (step + 1)]);
+          build_w(nbuf, step + 1, 1, kw1, kbox[2 * (step + 1) + 1]);
+          char* nb = smem + nbuf * L::BUF;
+#pragma unroll
+          for (int k = 0; k < NSTP; ++k) *reinterpret_cast<u32x4*>(nb + st_dst[k]) = st[k];
+        }
+        __syncthreads();
+      }
+      return;
+    }
+    // ---- the row-block waves ----
+    __syncthreads();   // step 0 is staged
+    for (int step = 0; step < n_main; ++step) {
+      const char* base = smem + (step & 1) * L::BUF;
+      // the tiles' geometry, computed once by the producer: one broadcast read each instead of ~40 instructions per wave
       const u32x4 cw0 = *reinterpret_cast<const u32x4*>(base + L::OFF_CT);
       const u32x4 cw1 = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + 16);
       const int ok0 = __builtin_amdgcn_readfirstlane((int)(cw0[0] & cw0[1])), ok1 = __builtin_amdgcn_readfirstlane((int)(cw1[0] & cw1[1]));
       const int x00 = __builtin_amdgcn_readfirstlane((int)cw0[2]), a00 = __builtin_amdgcn_readfirstlane((int)cw0[3]);
       const int x01 = __builtin_amdgcn_readfirstlane((int)cw1[2]), a01 = __builtin_amdgcn_readfirstlane((int)cw1[3]);
       if (ok0 | ok1) tiles(std::false_type{}, base, step, ok0, ok1, x00, a00, x01, a01);
-
-      if (more) {
-#if defined(BEVR_VARIANT) && BEVR_VARIANT == 2   // timing probe only (stale weights): what the builder wave costs the step
-        if (bld && step < 2) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
-#else
-        if (bld) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
-#endif
-        if (n_wave == 1) build_w(buf ^ 1, step + 1, 1 - tb, load_kw(step + 1, 1 - tb), sbo);
-        char* nb = smem + (buf ^ 1) * L::BUF;
-#pragma unroll
-        for (int k = 0; k < L::NST; ++k)
-          *reinterpret_cast<u32x4*>(nb + st_dst[k]) = st[k];
-        stage_direct(nb, step + 1, tid + L::NST * nt);
-      }
       __syncthreads();
     }
     if (n_main < n_step) {   // the peeled last step: padded keys masked
@@ -665,27 +645,30 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Vt
   typedef LdsC<PREC> L;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * d.S;
-  const int n_wave = d.Sp / 32;
-  const size_t lds = 2 * L::BUF + (size_t)n_wave * L::QSLOT;
-  if (!is16(PREC) && 64 * n_wave <= 512)
-    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
-                     (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O_in, LSE_in, O, LSE);
+  const int n_rb = d.Sp / 32;                 // one wave per 32-row block of the column ...
+  const int n_fast = n_rb + 1;                // ... + the producer wave (fast pass)
+  if (n_fast > 16) return BEVR_E_SHAPE;
+  const size_t lds = 2 * L::BUF + (size_t)n_fast * L::QSLOT;
+  if (!is16(PREC) && 64 * n_fast <= 512)
+    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_fast), lds, st,
+                       d, (const char*)Q, (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair,
+                       O_in, LSE_in, O, LSE);
   else
-    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false, 1024>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
-                     (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O_in, LSE_in, O, LSE);
+    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false, 1024>), dim3(grid), dim3(64 * n_fast), lds, st, d, (const char*)Q,
+                       (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O_in, LSE_in, O, LSE);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  // slow pass, in place: continues from the fast pass's state; its LDS also holds the list of slow tiles
-  const size_t lds_slow = lds + (size_t)(d.Np / 32) * 4;
+  // slow pass, in place: continues from the fast pass's state; no producer; its LDS also holds the list of slow tiles
+  const size_t lds_slow = 2 * L::BUF + (size_t)n_rb * L::QSLOT + (size_t)(d.Np / 32) * 4;
   if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
-  if (!is16(PREC) && 64 * n_wave <= 512)
-    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d, (const char*)Q,
-                     (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, (const float*)O,
-                     (const float*)LSE, O, LSE);
+  if (!is16(PREC) && 64 * n_rb <= 512)
+    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_rb), lds_slow, st,
+                       d, (const char*)Q, (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair,
+                       (const float*)O, (const float*)LSE, O, LSE);
   else
-    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true, 1024>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d, (const char*)Q,
-                     (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair, (const float*)O,
-                     (const float*)LSE, O, LSE);
+    hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true, 1024>), dim3(grid), dim3(64 * n_rb), lds_slow, st, d,
+                       (const char*)Q, (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair,
+                       (const float*)O, (const float*)LSE, O, LSE);
   return (int)hipGetLastError();
 }
 

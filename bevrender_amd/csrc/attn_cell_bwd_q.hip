@@ -120,7 +120,11 @@ __global__ __launch_bounds__(MAXT) void attn_cell_bwd_q_kernel(
   const int tid = threadIdx.x, nt = blockDim.x, n_wave = nt >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lq = lane & 31, hi = lane >> 5;
   const int Mp = d.S * d.Sp;
-  const int i0 = wave * 32;
+  // fast pass: the LAST wave is the workgroup's PRODUCER (attn_cell_fwd.hip): it stages the next step's keys and builds
+  // their weight tiles while the other waves (one per 32-row block) run the tiles; it owns no BEV rows (its row indices
+  // alias row block 0 so that the prologue stays in range; it leaves before anything is written)
+  const bool producer = !SLOW && wave == n_wave - 1;
+  const int i0 = (producer ? 0 : wave) * 32;
 
   const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 32 * EB;
   const char* dOh = dO + ((size_t)ph * Mp) * 32 * EB;
@@ -327,16 +331,6 @@ __global__ __launch_bounds__(MAXT) void attn_cell_bwd_q_kernel(
   };
 
   // ---- staging helpers -----------------------------------------------------------------------------------------
-  u32x4 st[L::NST];
-  const char* st_src[L::NST];
-  int st_inc[L::NST], st_dst[L::NST];
-#pragma unroll
-  for (int k = 0; k < L::NST; ++k) {
-    const int g = tid + k * nt;
-    // threads beyond the chunk count re-read chunk 0 into a dummy slot: loads and stores stay unconditional
-    chunk_map_q<PREC>(g < L::NCH ? g : 0, Kh, Vh, Kth, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
-    if (g >= L::NCH) st_dst[k] = L::OFF_DUMMY;
-  }
   auto stage_direct = [&](char* base, int step, int g0) {
     for (int g = g0; g < L::NCH; g += nt) {
       const char* src;
@@ -402,74 +396,63 @@ __global__ __launch_bounds__(MAXT) void attn_cell_bwd_q_kernel(
     auto load_kw = [&](int step, int t) {
       return *reinterpret_cast<const KeyW*>(kws + ((size_t)step * KT + t * 32 + lq) * sizeof(KeyW));
     };
-    auto builder_of = [&](int step, int t) { return (2 * step + t) % n_wave; };
-
     // W^T rows 16..31 of every tile stay zero (a chunk has 16 cells; the MFMA tile has 32 rows)
     for (int u = tid; u < 2 * 2 * 16 * (L::WT_STRIDE / 16); u += nt) {
       const int q16 = u % (L::WT_STRIDE / 16), row = (u / (L::WT_STRIDE / 16)) % 16, tb = u / (16 * (L::WT_STRIDE / 16));
       *reinterpret_cast<u32x4*>(smem + (tb >> 1) * L::BUF + L::OFF_WT + (tb & 1) * L::WT_TILE +
                                 (16 + row) * L::WT_STRIDE + q16 * 16) = u32x4{0, 0, 0, 0};
     }
-#pragma unroll
-    for (int k = 0; k < L::NST; ++k)
-      *reinterpret_cast<u32x4*>(smem + st_dst[k]) = gload16(st_src[k]);
-    stage_direct(smem, 0, tid + L::NST * nt);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-      if (builder_of(0, t) == wave) build_w(0, 0, t, load_kw(0, t), kbox[t]);
-    __syncthreads();
-
-    StepBox sb_nxt[2] = {kbox[2 * min(1, n_step - 1)], kbox[2 * min(1, n_step - 1) + 1]};
     // a last step with padded keys is peeled off behind the loop (its masked tile body inside the loop cost every tile
     // registers or hoisted compares)
     const int n_main = d.N < d.Np ? n_step - 1 : n_step;
-    for (int step = 0; step < n_main; ++step) {
-      const int buf = step & 1;
-      const char* base = smem + buf * L::BUF;
-      const bool more = step + 1 < n_step;
-      if (more) {
+    if (producer) {
+      // ---- the producer wave: global -> registers -> LDS one step ahead, and the weight tiles / geometry of the step
+      constexpr int NSTP = (L::NCH + 63) / 64;        // 16-byte chunks per lane and step
+      u32x4 st[NSTP];
+      const char* st_src[NSTP];
+      int st_inc[NSTP], st_dst[NSTP];
 #pragma unroll
-        for (int k = 0; k < L::NST; ++k) {
-#if defined(BEVR_VARIANT) && BEVR_VARIANT == 4   // timing probe: every step re-reads the first steps' (cache-hot) data
-          st_src[k] += (step < 8 ? st_inc[k] : 0);
-#else
-          st_src[k] += st_inc[k];
-#endif
-          st[k] = gload16(st_src[k]);
-        }
+      for (int k = 0; k < NSTP; ++k) {
+        const int g = lane + 64 * k;
+        // lanes beyond the chunk count re-read chunk 0 into a dummy slot: loads and stores stay unconditional
+        chunk_map_q<PREC>(g < L::NCH ? g : 0, Kh, Vh, Kth, kws, d.Np, st_src[k], st_inc[k], st_dst[k]);
+        if (g >= L::NCH) st_dst[k] = L::OFF_DUMMY;
       }
-      // the next step's key record for the tile this wave builds: unconditional load, consumed after the tiles
-      // (attn_cell_fwd.hip); a wave builds at most one tile of a step (two only when it is the only wave)
-      const int nstep_c = min(step + 1, n_step - 1);
-      const int tb = builder_of(step + 1, 1) == wave ? 1 : 0;
-      const bool bld = more && builder_of(step + 1, tb) == wave;
-      const KeyW kwn = load_kw(nstep_c, tb);
-      const StepBox sbb = sb_nxt[tb];
-      const StepBox sbo = sb_nxt[1 - tb];
-      sb_nxt[0] = kbox[2 * min(step + 2, n_step - 1)];
-      sb_nxt[1] = kbox[2 * min(step + 2, n_step - 1) + 1];
-
+#pragma unroll
+      for (int k = 0; k < NSTP; ++k) *reinterpret_cast<u32x4*>(smem + st_dst[k]) = gload16(st_src[k]);
+      build_w(0, 0, 0, load_kw(0, 0), kbox[0]);
+      build_w(0, 0, 1, load_kw(0, 1), kbox[1]);
+      __syncthreads();
+      for (int step = 0; step < n_main; ++step) {
+        if (step + 1 < n_step) {
+#pragma unroll
+          for (int k = 0; k < NSTP; ++k) {
+            st_src[k] += st_inc[k];
+            st[k] = gload16(st_src[k]);
+          }
+          const KeyW kw0 = load_kw(step + 1, 0), kw1 = load_kw(step + 1, 1);
+          const int nbuf = (step + 1) & 1;
+          build_w(nbuf, step + 1, 0, kw0, kbox[2 * (step + 1)]);
+          build_w(nbuf, step + 1, 1, kw1, kbox[2 * (step + 1) + 1]);
+          char* nb = smem + nbuf * L::BUF;
+#pragma unroll
+          for (int k = 0; k < NSTP; ++k) *reinterpret_cast<u32x4*>(nb + st_dst[k]) = st[k];
+        }
+        __syncthreads();
+      }
+      return;
+    }
+    // ---- the row-block waves ----
+    __syncthreads();   // step 0 is staged
+    for (int step = 0; step < n_main; ++step) {
+      const char* base = smem + (step & 1) * L::BUF;
 #pragma unroll 1
       for (int t = 0; t < 2; ++t) {
-        const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);   // geometry, by the builder
+        const u32x4 cw = *reinterpret_cast<const u32x4*>(base + L::OFF_CT + t * 16);   // geometry, by the producer
         const int live = __builtin_amdgcn_readfirstlane((int)cw[0]), fast = __builtin_amdgcn_readfirstlane((int)cw[1]);
         if (!live || !fast) continue;   // nothing to do / the slow pass's tile (uniform)
         tile(std::false_type{}, base, step, t, __builtin_amdgcn_readfirstlane((int)cw[2]),
              __builtin_amdgcn_readfirstlane((int)cw[3]));
-      }
-
-      if (more) {
-#if defined(BEVR_VARIANT) && BEVR_VARIANT == 2   // timing probe only (stale weights): what the builder wave costs the step
-        if (bld && step < 2) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
-#else
-        if (bld) build_w(buf ^ 1, step + 1, tb, kwn, sbb);
-#endif
-        if (n_wave == 1) build_w(buf ^ 1, step + 1, 1 - tb, load_kw(step + 1, 1 - tb), sbo);
-        char* nb = smem + (buf ^ 1) * L::BUF;
-#pragma unroll
-        for (int k = 0; k < L::NST; ++k)
-          *reinterpret_cast<u32x4*>(nb + st_dst[k]) = st[k];
-        stage_direct(nb, step + 1, tid + L::NST * nt);
       }
       __syncthreads();
     }
@@ -507,28 +490,30 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt
   typedef LdsCQ<PREC> L;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * d.S;
-  const int n_wave = d.Sp / 32;
-  const size_t lds = 2 * L::BUF + (size_t)n_wave * L::QSLOT;
-  const size_t lds_slow = lds + (size_t)(d.Np / 32) * 4;
+  const int n_rb = d.Sp / 32;                 // one wave per 32-row block of the column ...
+  const int n_fast = n_rb + 1;                // ... + the producer wave (fast pass)
+  if (n_fast > 16) return BEVR_E_SHAPE;
+  const size_t lds = 2 * L::BUF + (size_t)n_fast * L::QSLOT;
+  const size_t lds_slow = 2 * L::BUF + (size_t)n_rb * L::QSLOT + (size_t)(d.Np / 32) * 4;
   if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
-  if (!is16(PREC) && 64 * n_wave <= 512)
-    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
-                     (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
-                     (const char*)dO, LSE, delta, gs, dQ, dtable);
+  if (!is16(PREC) && 64 * n_fast <= 512)
+    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_fast), lds, st,
+                       d, (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
+                       (const char*)table_pair, (const char*)dO, LSE, delta, gs, dQ, dtable);
   else
-    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false, 1024>), dim3(grid), dim3(64 * n_wave), lds, st, d, (const char*)Q,
-                     (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
-                     (const char*)dO, LSE, delta, gs, dQ, dtable);
+    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false, 1024>), dim3(grid), dim3(64 * n_fast), lds, st, d, (const char*)Q,
+                       (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair,
+                       (const char*)dO, LSE, delta, gs, dQ, dtable);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  if (!is16(PREC) && 64 * n_wave <= 512)
-    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d,
-                     (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
-                     (const char*)table_pair, (const char*)dO, LSE, delta, gs, dQ, dtable);
+  if (!is16(PREC) && 64 * n_rb <= 512)
+    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_rb), lds_slow, st,
+                       d, (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
+                       (const char*)table_pair, (const char*)dO, LSE, delta, gs, dQ, dtable);
   else
-    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true, 1024>), dim3(grid), dim3(64 * n_wave), lds_slow, st, d,
-                     (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
-                     (const char*)table_pair, (const char*)dO, LSE, delta, gs, dQ, dtable);
+    hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, true, 1024>), dim3(grid), dim3(64 * n_rb), lds_slow, st, d,
+                       (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,
+                       (const char*)table_pair, (const char*)dO, LSE, delta, gs, dQ, dtable);
   return (int)hipGetLastError();
 }
 

@@ -1,7 +1,7 @@
 // Attention backward, query side, over a CELL-SORTED key segment (attn_cell.h): dQ and the rpe-table gradient.
 // Counterpart of attn_bwd_q.hip for keys whose 32-key tiles fit one table chunk; same operand layouts, same gradient
-// semantics (include/bevrender_hip.h), same work split as attn_cell_fwd.hip (workgroup = one BEV column, waves = its
-// 32-row blocks; one wave builds the next step's weights and tile geometry for all).
+// semantics (include/bevrender_hip.h), same work split as attn_cell_fwd.hip (workgroup = one BEV column: one wave per
+// 32-row block + a producer wave that stages the next step and builds its weights, their transposes and the tile geometry).
 //
 // The table gradient of a tile is the transpose of its bias product:
 //   dTsh[k'][i] += sum_n W[n][k'] dS^T[n][i]          (k' = chunk cell, i = BEV row of the lane)

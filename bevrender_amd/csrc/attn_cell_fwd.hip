@@ -3,11 +3,13 @@
 // (model/SCA_deform_attn.py:331-413 of the reference), same operand layouts, same orientation (S^T[key][query],
 // query on the lane, online softmax, P^T fed back as the B operand of PV).
 //
-// Work split: workgroup = ONE BEV column j of one (problem, head); its waves are the column's 32-row blocks, so every
-// wave needs the same per-(column, key) weights W and the same tile geometry: one wave (rotating) builds both for the
-// next step while all waves compute the current one, and they are handed over in LDS with the staged K / V^T tiles
-// (one barrier per 64-key step).  A wave reloads its table operand only when the chunk origin changes (3 % of the
-// tiles of a cell-sorted segment).
+// Work split: workgroup = ONE BEV column j of one (problem, head): one wave per 32-row block of the column + one
+// PRODUCER wave.  Every row-block wave needs the same per-(column, key) weights W, the same tile geometry and the same
+// staged K / V^T tiles: the producer fetches the next step's keys (global -> registers -> LDS) and builds W and the
+// geometry for it while the row-block waves compute the current step; one barrier per 64-key step hands the buffer over.
+// (With the staging shared by all waves and a rotating builder wave the kernel was 25 % slower: every wave carried
+// staging registers and instructions, and the builder arrived last at every barrier.)  A row-block wave reloads its
+// table operand only when the chunk origin changes (3 % of the tiles of a cell-sorted segment).
 //
 // The kernel is VALU-bound (a wave64 VALU instruction holds the SIMD ~4.4 clk; measured, profiles/r03_pmc_*), so the
 // tile body is written for instruction count: the MFMA chains start from a literal-zero accumulator and the row

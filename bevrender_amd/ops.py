@@ -593,8 +593,11 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
         raise ValueError("cell_split must lie in [0, N]")
     geom = AttnGeom(n_prob=Bp, q_div=views, heads=heads, groups=groups, S=S, N=N, Wt=rpe_table.shape[-1],
                     precision=precision)
-    if split < N and geom.Sp > 480:
-        split = N                       # the cell kernels run one wave per 32-row block of a BEV column + a producer wave: 16 at most
+    f32_layout = precision in (_lib.PREC_F32, _lib.PREC_BF16X3)
+    if split < N and (geom.Sp > 480 or (f32_layout and geom.Sp > 256)):
+        # the cell kernels run one wave per 32-row block of a BEV column + a producer wave, 16 at most; with f32-sized
+        # operands the query-side backward's LDS (2 staging buffers + a Q / dO slot per wave) ends at 8 row blocks
+        split = N
     if rpe_table.shape[-2] != 2 * S - 1:
         raise ValueError("rpe_table height must be 2S-1")
     Qp = pack_query(query.float(), heads)

@@ -179,7 +179,10 @@ int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, cons
  * of 32 span fewer than 4 table columns and 4 table rows including their second taps -- what sorting keys that
  * crowd a few table cells by cell gives (the pillar points a camera does not see are all pinned to pixel (0, 0),
  * model/bev_cmr_proj.py:76 of the reference: two thirds of an SCA view's keys) -- correct for any keys (runs that do
- * not fit are gathered per pair from the table in global memory).  Requires Sp <= 512.
+ * not fit are gathered per pair from the table in global memory).  A workgroup is one BEV column: a wave per 32-row
+ * block + a producer wave, 16 at most, and a Q (+ dO) slot per wave in LDS: BEVR_E_SHAPE for Sp > 480, and from
+ * bevr_attn_cell_bwd_q with float-sized operands (BEVR_PREC_F32, BEVR_PREC_BF16X3) for Sp > 256 (160 KB of LDS); the
+ * caller then keeps every key on the region entry points (bevrender_amd/ops.py:attention_core does).
  *
  * One softmax over two key segments: run bevr_attn_fwd on the scattered keys, then bevr_attn_cell_fwd on the sorted
  * ones with (O_in, LSE_in) = the first call's (O, LSE plane 0): the result is the softmax over both.  O_in == NULL:

@@ -467,7 +467,8 @@ def test_encoder_layer_s56_matches_reference(prec):
                       atol_frac=1e-3 if f32 else 5e-2, floor_frac=2e-5 if f32 else 2e-3)
 
 
-@pytest.mark.parametrize("prec", [_lib.PREC_F16, _lib.PREC_BF16])
+# BF16X3: the f32-layout cell kernels at 14 waves per workgroup run their 1024-thread instantiation here
+@pytest.mark.parametrize("prec", [_lib.PREC_F16, _lib.PREC_BF16, _lib.PREC_BF16X3])
 def test_cfg5_geometry_bev400_rows_and_gradients(prec):
     """The S = 400 geometry of BASELINE config 5 (M = 160 000, N = 400 000 per view, table 799 x 3999), one view, in
     the fp16 operand mode the config names (and in bf16):

@@ -202,6 +202,54 @@ int bevr_attn_cell_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt,
                          float* dkey_a, float* dkey_b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * TAP entry points (csrc/attn_tap.h): the same attention for a key segment whose keys all SAMPLE INSIDE THE TOP-LEFT
+ * 4 x 3 PIXELS of their feature map -- the pillar points a camera does not see: the projector pins them to pixel (0, 0)
+ * (model/bev_cmr_proj.py:76) and the learned offset moves them by less than +-2.5 (Hi-1)/(Hk-1) x +-2.5 (Wi-1)/(Wk-1)
+ * pixels (model/SCA_deform_attn.py:261-277).  For those keys K_n = sum_t w_t(n) Kpix_t + bk and V_n alike (bilinear
+ * weights w_t over the 12 pixels t = 3 r + c; proj_k / proj_v are linear), so K and V are never formed:
+ *   logits  S[n][q] = sum_t w_t(n) G[t][q] + Gb[q] + bias[n][q],     G[t][q] = Q_q . Kpix_t (Q pre-scaled), Gb = Q_q . bk
+ *   output  O_q     = sum_t Rn[t][q] Vpix_t + bv,                    Rn = R / R[15],  R[t][q] = sum_n w_t(n) P[n][q]
+ * The caller forms G, Gb (thin GEMMs) before and O after the launch, and merges the segment with the other keys of the
+ * same softmax through (mref, R[15]): the segment's log2-sum-exp is mref[q] + log2 R[15][q].
+ * Geometry, table, descriptor (groups == 1, precision BEVR_PREC_BF16 or BEVR_PREC_F16) as above; keys cell-sorted for
+ * speed (any key set is handled: a 32-key run that does not fit one table chunk is processed in several masked passes).
+ *   key_a, key_b, key_y, key_x [n_prob][Np] float: table coordinates as above; sampling position in FEATURE PIXELS
+ *       ys = (py + 1)/2 (Hi - 1), xs likewise (ys < 3 and xs < 2 or outside the image: the caller's contract)
+ *   tap_ws: bevr_attn_tap_ws_bytes(d) bytes, written by bevr_attn_tap_prep, opaque
+ *   G   [n_prob][heads][Mp][16] E: slots 0..11 the taps; slots 12, 13 the hi and lo 16-bit parts of the row's logit
+ *       offset c = Gb[q] - mref[q] (hi = E(c), lo = E(c - hi): the matrix product adds them against ones on the key side);
+ *       slot 14 = -1e30 (E = bf16) / -60000 (fp16): the logit of a masked key; slot 15 zero
+ *   mref [n_prob][heads][Mp] float IN/OUT: the softmax reference of each row, AS THE KERNEL SEES IT (Gb - (hi + lo)).  In:
+ *       an upper bound of the row's logits minus a headroom of <= 100 (no weight can then overflow; bevrender_amd/ops.py
+ *       uses max(0, max_t G) + Gb + max(0, max table) - 64).  Out: the reference R is relative to -- unchanged unless
+ *       every weight of the row underflowed against the bound (looser than ~190 binades), in which case the column is
+ *       recomputed with an online maximum and its rows' mref are replaced.
+ *   R   [n_prob][heads][Mp][16] float (written; rows 12, 13 equal row 15)   flags [n_prob*heads][S] int32, ZEROED by the
+ *       caller (scratch)
+ * ---------------------------------------------------------------------------------------------- */
+size_t bevr_attn_tap_ws_bytes(const bevr_attn_desc* d);
+int bevr_attn_tap_prep(const bevr_attn_desc* d, const float* key_a, const float* key_b, const float* key_y,
+                       const float* key_x, void* tap_ws, void* stream);
+int bevr_attn_tap_fwd(const bevr_attn_desc* d, const void* G, const void* tap_ws, const float* table_pair, float* mref,
+                      float* R, int32_t* flags, void* stream);
+/* Query-side backward.  With P[n][q] = exp2(S[n][q] - LSE[q]) (LSE: the log2-sum-exp over ALL key segments of the softmax):
+ *     dS[n][q] = P[n][q] (sum_t w_t(n) H[t][q] + Hc[q]),     dG[k][q] = sum_n A[n][k] dS[n][q]   (A = the 16 slot weights)
+ *   G as above with the offset c = Gb - LSE in slots 12, 13 (padding rows i >= S: c <= -1e30, their weights vanish)
+ *   H  [n_prob][heads][Mp][16] E = ln2 * (dO_q . Vpix_t) in slots 0..11, the hi and lo parts of Hc = ln2 * (dO_q . bv - delta_q)
+ *      in slots 12, 13, zero in 14, 15
+ *   dG [n_prob][heads][Mp][16] float WRITTEN: slots 0..11 the gradient of G, slot 15 the gradient of Gb
+ *   dtable as bevr_attn_bwd_q: ACCUMULATED (float atomics). */
+int bevr_attn_tap_bwd_q(const bevr_attn_desc* d, const void* G, const void* H, const void* tap_ws,
+                        const float* table_pair, float* dG, float* dtable, void* stream);
+/* Key-side backward: the gradients of every key's table coordinates and sampling position (G, H as bevr_attn_tap_bwd_q),
+ *   dkey_a, dkey_b, dkey_y, dkey_x [n_prob][Np] float, ACCUMULATED over the heads (caller zeroes them):
+ *   d/d key_a, d/d key_b through the bias (bilinear derivative of the table), d/d key_y, d/d key_x through the tap
+ *   weights -- both paths of it: the logits (G) and the values (H carries dO . Vpix).  Kinks as F.grid_sample's backward
+ *   (floor-based: the derivative of the tap pair the position sits between). */
+int bevr_attn_tap_bwd_k(const bevr_attn_desc* d, const void* G, const void* H, const void* tap_ws,
+                        const float* table_pair, float* dkey_a, float* dkey_b, float* dkey_y, float* dkey_x, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Bilinear feature sampling, align_corners=True, zero padding (grid_sample semantics).
  *   feat [nb][Hi][Wi][C] float (channels-last)     pos [nb][N][2] float, (y, x) in [-1, 1] units
  *   out  [nb][N][C] float

@@ -1,7 +1,7 @@
 // Key-side backward of the tap kernels (attn_tap.h): the gradient of every key's POSITION -- its rpe-table coordinates
 // (a, b) through the bias and its sampling position (ys, xs) through the tap weights.  With P and dS as in
 // attn_tap_bwd_q.hip (dS = P (w . H + Hc), ln2 and delta folded into H by the caller),
-//     dw_t(n) = sum_q dS[n][q] G[t][q] + P[n][q] H[t][q]        (the logit path and the value path V_n = sum_t w_t Vpix_t)
+//     dw_t(n) = sum_q dS[n][q] G[t][q] + P[n][q] H[t][q] / ln2  (the logit path and the value path V_n = sum_t w_t Vpix_t)
 //     Z[cell][n] = sum_q dS[n][q] Tsh[cell][q]                  per BEV column: the chunk's cells are a different part of the
 //                                                                table for every column
 //     d a_n = sum_c wx_c (Z[c][r0 + 1] - Z[c][r0]),   d b_n = sum_r wy_r (Z[c0 + 1][r] - Z[c0][r])     (bilinear derivative)
@@ -33,7 +33,18 @@ struct LdsK {
 // dwords per (kind, parity, column) of a window: rows 0 .. Sp + NRX + 7, two rows per dword
 __host__ __device__ __forceinline__ int win_dwords(int Sp) { return (Sp + NRX + 8) / 2; }
 
-template <int PREC>
+// does tile box `sb` take the matrix path in BEV column j?  Its taps fit one chunk, and the chunk lies inside the
+// workgroup's window (origin row a0w, leftmost coordinate bminw)
+__device__ __forceinline__ bool tile_fits(const StepBox& sb, float jrx, int a0w, float bminw) {
+  const int da = sb.amin - a0w;
+  const int dx = (int)floorf(jrx + sb.bmin) - (int)floorf(jrx + bminw);
+  return sb.amax >= sb.amin && da >= 0 && da <= NRX && box_fits(sb, jrx) && dx >= 0 && dx <= NCW - CELL_C;
+}
+
+// SLOW = false: the (tile, column) pairs that take the matrix path; SLOW = true: the others, by the per-pair gather (a
+// workgroup without any leaves at once: every workgroup of a cell-sorted segment).  Two launches: with both bodies in one
+// loop the matrix path reloaded loop invariants from scratch on every slab.
+template <int PREC, bool SLOW>
 __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
     bevr_attn_desc d, const char* __restrict__ G, const char* __restrict__ H, const char* __restrict__ tap_ws,
     const float* __restrict__ table_t, float* __restrict__ dkey_a, float* __restrict__ dkey_b,
@@ -60,6 +71,8 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
   const int NRWD = win_dwords(d.Sp);
   const int win_bytes = 4 * NCW * NRWD * 4;                   // [kind hi / lo][row parity][NCW columns][NRWD dwords]
   char* win_base = smem + 2 * L::BUF;
+  // the key waves' records live in LDS between their uses (column start, column end): 8 registers less in the slab loop
+  TapRec* stash = reinterpret_cast<TapRec*>(win_base + 3 * win_bytes) + wave * 32;
 
   // the workgroup's window origin: the lowest table row / leftmost coordinate of its tiles (rows: for every column)
   int a0w = 0x7fffffff;
@@ -75,6 +88,17 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
     }
   }
   if (a0w == 0x7fffffff) { a0w = 0; bminw = 0.f; }
+  if constexpr (SLOW) {
+    bool unfit = false;     // the same for every wave of the workgroup: all of them leave, or none
+    for (int t = 0; t < NKW; ++t) {
+      const int tile = wg * NKW + t;
+      if (tile >= n_tiles) break;
+      const StepBox b = box[tile];
+      if (b.amax < b.amin) continue;
+      for (int j = lane; j < d.S; j += 64) unfit = unfit || !tile_fits(b, (float)j * rx, a0w, bminw);
+    }
+    if (!__any(unfit)) return;
+  }
 
   if (wave == NKW) {
     // ---- producer: the G and H rows of slab (j, i0) -> LDS one step ahead of the key waves, and the table window of the
@@ -110,7 +134,8 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
         w[3 * NCW * NRWD + 1] = l34;
       }
     };
-    for (int it = lane; it < n_item; it += 64) fill(0, it);
+    if constexpr (!SLOW)
+      for (int it = lane; it < n_item; it += 64) fill(0, it);
     const char* Gp = G + ((size_t)ph * Mp) * 32 + lane * 16;
     const char* Hq = H + ((size_t)ph * Mp) * 32 + lane * 16;
     int e = 0;
@@ -123,8 +148,10 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
         const int e2 = min(e + 1, d.S * nslab - 1);     // the next slab's rows are in flight across the barrier
         gv = gload16(Gp + (size_t)e2 * 1024);
         hv = gload16(Hq + (size_t)e2 * 1024);
-        if (j + 1 < d.S)
-          for (int it = lane + 64 * s; it < n_item; it += 64 * nslab) fill(j + 1, it);
+        if constexpr (!SLOW) {
+          if (j + 1 < d.S)
+            for (int it = lane + 64 * s; it < n_item; it += 64 * nslab) fill(j + 1, it);
+        }
         __syncthreads();
       }
     }
@@ -139,19 +166,21 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
   const int tl = have_tile ? tile : 0;
   const StepBox sb = box[tl];
   const int da = sb.amin - a0w;                       // rows between the window's origin and this tile's chunk origin
-  const bool rows_ok = sb.amax >= sb.amin && da >= 0 && da <= NRX;
 
-  TapRec rc[2];
   bf16x8 bk[2];        // B operand of S / dP for key sub-tile kb: lanes 0..31 the tap slots, lanes 32..63 the cells (per column)
-  f32x4 zt[2], zc[2];  // Z[slot 4 g + e][key], Z[cell (c = g, r = e)][key]
+  // Z[slot 4 g + e][key] of the logit path (G^T dS) and of the value path (H^T P: H carries ln2, undone at the end),
+  // Z[cell (c = g, r = e)][key]
+  f32x4 zt[2], zv[2], zc[2];
   float acc_a[2] = {0.f, 0.f}, acc_b[2] = {0.f, 0.f};
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    rc[kb] = recs[(size_t)tl * 32 + 16 * kb + li];
+    const TapRec r0 = recs[(size_t)tl * 32 + 16 * kb + li];
+    if (g == 0) stash[16 * kb + li] = r0;
     u32x4 t0, t1;
-    tap_weights<PREC>(rc[kb].ys, rc[kb].xs, t0, t1);
+    tap_weights<PREC>(r0.ys, r0.xs, t0, t1);
     bk[kb] = __builtin_bit_cast(bf16x8, g == 0 ? t0 : t1);
     zt[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    zv[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
     zc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int a_row = L::OFF_G + li * 32 + (g & 1) * 16;                          // row read of a staged image (lanes 0..31)
@@ -205,10 +234,11 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
       const f32x4 q1 = mfma16<PREC>(ha[1], bk[kb], z4);
       float p[8], ds[8];
       if constexpr (!FIT) {
-        const float a = rc[kb].a, tx = jrx + rc[kb].b;
+        const TapRec rk = stash[16 * kb + li];
+        const float a = rk.a, tx = jrx + rk.b;
         const float af = floorf(a), xf = floorf(tx);
         const float fy = a - af, fx = tx - xf;
-        const bool dead = rc[kb].ys < -50.0f;
+        const bool dead = rk.ys < -50.0f;
         const int xc = max(0, min((int)xf + d.x_off, d.Wp - 2));
         const int yb = (int)af + d.y_off + i0 + 4 * g;
         float pa = 0.f, pb = 0.f;
@@ -243,7 +273,7 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
       }
       const bf16x8 ds8 = __builtin_bit_cast(bf16x8, dsw), p8 = __builtin_bit_cast(bf16x8, pw);
       zt[kb] = mfma16<PREC>(gt, ds8, zt[kb]);
-      zt[kb] = mfma16<PREC>(ht, p8, zt[kb]);
+      zv[kb] = mfma16<PREC>(ht, p8, zv[kb]);
       if constexpr (FIT) {
         zc[kb] = mfma16<PREC>(tlo, ds8, zc[kb]);
         zc[kb] = mfma16<PREC>(thi, ds8, zc[kb]);
@@ -255,18 +285,25 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
     jrx = (float)j * rx;
     const int x0 = (int)floorf(jrx + sb.bmin), a0 = sb.amin;
     const int dx = x0 - (int)floorf(jrx + bminw);
-    const bool fit = have_tile && rows_ok && box_fits(sb, jrx) && dx >= 0 && dx <= NCW - CELL_C;   // uniform over the wave
-    float tcol[2], trow[2];
+    const bool fit = tile_fits(sb, jrx, a0w, bminw);    // uniform over the wave
+    const bool mine = have_tile && sb.amax >= sb.amin && fit != SLOW;   // this launch's share of the (tile, column) pairs
+    // this key's coordinates inside the chunk for this column
+    auto chunk_coords = [&](int kb, float& tcol, float& trow) {
+      const TapRec rk = stash[16 * kb + li];
+      const float tx = jrx + rk.b;
+      const float xf = floorf(tx);
+      tcol = rk.ys < -50.0f ? -8.0f : (xf - (float)x0) + (tx - xf);
+      trow = rk.a - (float)a0;
+    };
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      const float tx = jrx + rc[kb].b;
-      const float xf = floorf(tx);
-      const bool dead = rc[kb].ys < -50.0f;
-      tcol[kb] = dead ? -8.0f : (xf - (float)x0) + (tx - xf);
-      trow[kb] = rc[kb].a - (float)a0;
       if (g >= 2) {
         u32x4 cw = {0u, 0u, 0u, 0u};
-        if (fit) cw = __builtin_bit_cast(u32x4, cell_weights<PREC>(tcol[kb], trow[kb], g - 2).v);
+        if (!SLOW && mine) {
+          float tcol, trow;
+          chunk_coords(kb, tcol, trow);
+          cw = __builtin_bit_cast(u32x4, cell_weights<PREC>(tcol, trow, g - 2).v);
+        }
         bk[kb] = __builtin_bit_cast(bf16x8, cw);
       }
       zc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -274,16 +311,15 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
     win = reinterpret_cast<const uint32_t*>(win_base + (j % 3) * win_bytes) + dx * NRWD;
     for (int s = 0; s < nslab; ++s, ++e) {
       __syncthreads();
-      if (!have_tile) continue;
-      const char* base = smem + (e & 1) * L::BUF;
-      if (fit) slab(std::true_type{}, base, 32 * s);
-      else slab(std::false_type{}, base, 32 * s);
+      if (!mine) continue;
+      slab(std::integral_constant<bool, !SLOW>{}, smem + (e & 1) * L::BUF, 32 * s);
     }
     // ---- the column's bias-position gradients out of Z: this lane holds chunk column c = g, rows 0..3 of its key ----
-    if (fit) {
+    if (!SLOW && mine) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const float tc = tcol[kb], tr = trow[kb];
+        float tc, tr;
+        chunk_coords(kb, tc, tr);
         const float c0 = floorf(tc), r0 = floorf(tr);
         const float wxg = hat((float)g - tc);
         const float z0 = zc[kb][0], z1 = zc[kb][1], z2 = zc[kb][2], z3 = zc[kb][3];
@@ -303,7 +339,8 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
   // ---- per key: tap-weight gradients -> sampling-position gradient; everything summed over the four lane groups ----
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    const float ys = rc[kb].ys, xs = rc[kb].xs;
+    const TapRec rk = stash[16 * kb + li];
+    const float ys = rk.ys, xs = rk.xs;
     const float y0 = floorf(ys), x0f = floorf(xs);
     float gy = 0.f, gx = 0.f;
 #pragma unroll
@@ -312,7 +349,7 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
       const float r = (float)(t / 3), c = (float)(t % 3);
       const float dwy = (r == y0 + 1.0f ? 1.0f : 0.f) - (r == y0 ? 1.0f : 0.f);
       const float dwx = (c == x0f + 1.0f ? 1.0f : 0.f) - (c == x0f ? 1.0f : 0.f);
-      const float z = g < 3 ? zt[kb][e2] : 0.f;
+      const float z = g < 3 ? zt[kb][e2] + BEVR_LOG2E * zv[kb][e2] : 0.f;
       gy += z * dwy * hat(c - xs);
       gx += z * hat(r - ys) * dwx;
     }
@@ -337,11 +374,15 @@ int launch(const bevr_attn_desc& d, const void* G, const void* H, const void* ta
   const int n_ph = d.n_prob * d.heads;
   const int n_tiles = d.Np / 32;
   const int n_wg_ph = (n_tiles + NKW - 1) / NKW;
-  const size_t lds = 2 * L::BUF + (size_t)3 * 4 * NCW * win_dwords(d.Sp) * 4;
+  const size_t lds = 2 * L::BUF + (size_t)3 * 4 * NCW * win_dwords(d.Sp) * 4 + NKW * 32 * sizeof(TapRec);
   if (lds > 160 * 1024) return BEVR_E_SHAPE;
   const long long grid = (long long)((n_ph + 7) / 8) * 8 * n_wg_ph;
   if (grid > 0x7fffffffLL) return BEVR_E_SHAPE;
-  hipLaunchKernelGGL((attn_tap_bwd_k_kernel<PREC>), dim3((unsigned)grid), dim3(64 * (NKW + 1)), lds, st, d, (const char*)G,
+  hipLaunchKernelGGL((attn_tap_bwd_k_kernel<PREC, false>), dim3((unsigned)grid), dim3(64 * (NKW + 1)), lds, st, d, (const char*)G,
+                     (const char*)H, (const char*)tap_ws, table_t, dkey_a, dkey_b, dkey_y, dkey_x, n_wg_ph);
+  const int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL((attn_tap_bwd_k_kernel<PREC, true>), dim3((unsigned)grid), dim3(64 * (NKW + 1)), lds, st, d, (const char*)G,
                      (const char*)H, (const char*)tap_ws, table_t, dkey_a, dkey_b, dkey_y, dkey_x, n_wg_ph);
   return (int)hipGetLastError();
 }

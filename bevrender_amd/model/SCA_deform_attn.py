@@ -117,6 +117,20 @@ class SCADeformableAttention(nn.Module):
             pos = pos.gather(3, key_order[None, :, None, :, None].expand(B, V, g, N, 2))
         return pos
 
+    def _pinned_keys_tap(self, S, Hi, Wi):
+        """Do the keys the projector pins to pixel (0, 0) all sample inside the top-left 4 x 3 feature pixels (the tap
+        kernels' contract, csrc/attn_tap.h)?  Their position is the learned offset alone, tanh(.) * 5 / (Hk - 1) in y and
+        5 / (Wk - 1) in x (reference :261-277): at most +-2.5 (Hi - 1) / (Hk - 1) x +-2.5 (Wi - 1) / (Wk - 1) pixels.
+        Without the tanh range the positions are only clamped to the image: no bound, no tap kernels."""
+        if not (self.scale_offset_range and ops.tap_supported(self.precision, self.n_groups)):
+            return False
+        Hk, Wk = S // 2, S * self.bev_depth_dim
+        if Hk < 2 or Wk < 2:
+            return False
+        ymax = 0.5 * self.offset_range_factor / (Hk - 1.0) * (Hi - 1)
+        xmax = 0.5 * self.offset_range_factor / (Wk - 1.0) * (Wi - 1)
+        return (ymax < ops.TAP_R - 1 - 1e-3 or Hi <= ops.TAP_R) and (xmax < ops.TAP_C - 1 - 1e-3 or Wi <= ops.TAP_C)
+
     def forward(self, x, query, reference_points, wandb_log_dict, return_wandb_log=True, key_order=None,
                 cell_split=None):
         """x (B, V, C, Hi, Wi); query (B, C, S, S); reference_points (B, V, S/2, S*D, 2) in (x, y).
@@ -154,7 +168,8 @@ class SCADeformableAttention(nn.Module):
             # nor the projected rows reach HBM.  The channels-last view of the backbone's output is read as it is
             feat = (xf if xf.dtype == torch.bfloat16 else xf.float()).permute(0, 2, 3, 1).contiguous()
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
-                                   precision=self.precision, kv_source=(feat, Wkv, bkv), cell_split=cell_split)
+                                   precision=self.precision, kv_source=(feat, Wkv, bkv), cell_split=cell_split,
+                                   tap_source=cell_split is not None and self._pinned_keys_tap(S, Hi, Wi))
         else:
             xs = ops.sample_features(xf, pos, g)                                     # (B*V, N, C)
             kv = F.linear(xs, Wkv, bkv)

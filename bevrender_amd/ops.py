@@ -379,7 +379,8 @@ class _AttnCore(torch.autograd.Function):
             segs.append(_Seg(True, split, dc_replace(geom, N=N - split)))
         Ttc = Tt.contiguous()
         pair = torch.stack((Ttc[..., :-1], Ttc[..., 1:]), dim=-1).contiguous()   # (h, Wp, Hp, 2)
-        O = torch.empty(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
+        # zeros: the rows past the grid are never written, and a merge with another segment multiplies them by weight 0
+        O = torch.zeros(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
         # plane 0: log2-sum-exp; plane 1: a bound of log2 of the row's largest softmax weight (rows past the grid: -inf here)
         LSE = torch.full((2, geom.n_prob, geom.heads, geom.Mp), float("-inf"), device=dev, dtype=torch.float32)
         need_bwd = any(ctx.needs_input_grad)
@@ -433,10 +434,13 @@ class _AttnCore(torch.autograd.Function):
             saved += [feat, spos, Wkv, vn2] + ([bkv] if bkv is not None else [])
             ctx.has_bias = bkv is not None
         ctx.save_for_backward(Qe, pair, O, LSE, *saved)
-        return O
+        ctx.set_materialize_grads(False)
+        # second output: the rows' log2-sum-exp (plane 0).  Differentiable: a caller that merges this softmax with
+        # another key segment (attention_core(tap_source=...)) sends a cotangent back, which enters delta below
+        return O, LSE[0].clone()
 
     @staticmethod
-    def backward(ctx, dO):
+    def backward(ctx, dO, dLSE=None):
         geom: AttnGeom = ctx.geom
         Qe, pair, O, LSE, *saved = ctx.saved_tensors
         if ctx.fused:
@@ -444,6 +448,8 @@ class _AttnCore(torch.autograd.Function):
             saved = saved[:ctx.n_seg_saved]
         L = _lib.lib()
         ed = _edtype(geom.precision)
+        if dO is None:
+            dO = torch.zeros_like(O)
         dO = dO.contiguous()
         f16 = geom.precision == _lib.PREC_F16
         if f16:
@@ -458,7 +464,12 @@ class _AttnCore(torch.autograd.Function):
         # cancels as it must where P -> 1 (with the f32 dO here and the bf16 one there, |dS| kept a floor of
         # 2^-9 |dO||V| -- pure noise in dQ, dK, d(pos), d(table) of a row dominated by one key)
         dOr = dO.float() if x3 else dOe.float()
-        delta = (dOr * O).sum(-1).contiguous()
+        delta = (dOr * O).sum(-1)
+        if dLSE is not None:
+            # outputs (O, LSE2): d logit = ln2 P (dO . V - dO . O) + P dLSE2 = ln2 P (dP - (delta - dLSE2 / ln2))
+            dl = torch.where(torch.isfinite(LSE[0]), dLSE.float(), torch.zeros_like(delta)) * LOG2E
+            delta = delta - (dl * sdo if f16 else dl)
+        delta = delta.contiguous()
         dev = dO.device
         # zeros: bwd_q walks the grid in 31-row tiles and never visits the padded rows S..Sp-1 of a column; the cell
         # kernels add their segment's share
@@ -553,7 +564,8 @@ class _AttnCore(torch.autograd.Function):
 
 def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Optional[torch.Tensor], pos: torch.Tensor,
                    rpe_table: torch.Tensor, *, heads: int, groups: int, views: int, precision: int,
-                   kv: Optional[torch.Tensor] = None, cell_split: Optional[int] = None, kv_source=None) -> torch.Tensor:
+                   kv: Optional[torch.Tensor] = None, cell_split: Optional[int] = None, kv_source=None,
+                   tap_source=None) -> torch.Tensor:
     """Fused attention of the BEV query against sampled keys.
 
     query (B, C, S, S) layer-normed BEV query (used raw as Q); kproj, vproj (B*views, N, C) projected
@@ -566,6 +578,10 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     (float or bf16) the keys are sampled from AT `pos`, Wkv (2C, C) / bkv (2C,) the proj_k | proj_v weights: sampling,
     projection and operand packing run as one kernel (csrc/kvproj.hip; groups == 1, 16-bit operand modes -- see
     kv_source_supported).
+    tap_source = True (with kv_source and cell_split): the keys [cell_split, N) all sample inside the top-left 4 x 3
+    pixels of `feat` (the caller's contract: the projector-pinned keys, tap_supported) and go through the TAP kernels
+    (csrc/attn_tap.h): their K and V are never formed -- the logits come from G = Q Kpix^T (12 pixels), the output from
+    O = Rn Vpix, both thin GEMMs here -- and the segment is merged with the region kernels' through (O, LSE).
     Returns (B*views, S*S, C): per view softmax(QK^T c^-0.5 + bias) V, rows in i*S + j order.
     Replaces model/SCA_deform_attn.py:304-413 / model/TSA_deform_attn.py:220-333.
     """
@@ -591,23 +607,163 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     split = N if cell_split is None else int(cell_split)
     if not 0 <= split <= N:
         raise ValueError("cell_split must lie in [0, N]")
-    geom = AttnGeom(n_prob=Bp, q_div=views, heads=heads, groups=groups, S=S, N=N, Wt=rpe_table.shape[-1],
-                    precision=precision)
+    Wt = rpe_table.shape[-1]
+    if rpe_table.shape[-2] != 2 * S - 1:
+        raise ValueError("rpe_table height must be 2S-1")
+    tap = bool(tap_source) and split < N
+    if tap and (kv_source is None or not tap_supported(precision, groups) or 16 * ((S + 15) // 16) > 448):
+        raise ValueError("tap_source needs kv_source, groups == 1, the bf16 operand mode and S <= 448")
+    geom = AttnGeom(n_prob=Bp, q_div=views, heads=heads, groups=groups, S=S, N=split if tap else N, Wt=Wt, precision=precision)
     f32_layout = precision in (_lib.PREC_F32, _lib.PREC_BF16X3)
-    if split < N and (geom.Sp > 480 or (f32_layout and geom.Sp > 256)):
+    if not tap and split < N and (geom.Sp > 480 or (f32_layout and geom.Sp > 256)):
         # the cell kernels run one wave per 32-row block of a BEV column + a producer wave, 16 at most; with f32-sized
         # operands the query-side backward's LDS (2 staging buffers + a Q / dO slot per wave) ends at 8 row blocks
         split = N
-    if rpe_table.shape[-2] != 2 * S - 1:
-        raise ValueError("rpe_table height must be 2S-1")
     Qp = pack_query(query.float(), heads)
-    a, b = key_coords(pos.float(), S, geom.Wt, N)
+    a, b = key_coords(pos.float(), S, Wt, N)
     Tt = pack_table(rpe_table.float(), geom)
-    if kv_source is not None:
-        O = _AttnCore.apply(Qp, None, a, b, Tt, geom, split, feat, pos.float(), Wkv, bkv)
-    else:
-        O = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split, None, None, None, None)
+    if not tap:
+        if kv_source is not None:
+            O, _ = _AttnCore.apply(Qp, None, a, b, Tt, geom, split, feat, pos.float(), Wkv, bkv)
+        else:
+            O, _ = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split, None, None, None, None)
+        return unpack_out(O, S, c)
+
+    # ---- keys [0, split): region kernels; keys [split, N): tap kernels; one softmax, merged through (O, LSE) ----
+    V = views
+    Hi, Wi = feat.shape[1], feat.shape[2]
+    O_r = LSE_r = None
+    if split > 0:
+        O_r, LSE_r = _AttnCore.apply(Qp, None, a[:, :split], b[:, :split], Tt, geom, split, feat,
+                                     pos[:, :split].float().contiguous(), Wkv, bkv)
+    # the 12 pixels' K | V rows, without the bias: (B', 12, 2C); rows the image does not have are zero (zero padding)
+    fpix = feat[:, :TAP_R, :TAP_C, :].float()
+    fpix = F.pad(fpix, (0, 0, 0, TAP_C - fpix.shape[2], 0, TAP_R - fpix.shape[1])).reshape(Bp, TAP_N, Cc)
+    kvp = F.linear(fpix, Wkv.float())
+    pad_c = HEAD_DIM - c
+    # G[q][t] = Q_q . Kpix_t per (sample, view, head): one GEMM per (sample, head) against the views' 12 pixels side by side
+    Kp = F.pad(kvp[..., :Cc].reshape(B, V, TAP_N, heads, c), (0, pad_c)).permute(0, 3, 4, 1, 2).reshape(B, heads, HEAD_DIM, V * TAP_N)
+    G = torch.matmul(Qp, Kp).reshape(B, heads, geom.Mp, V, TAP_N).permute(0, 3, 1, 2, 4).reshape(Bp, heads, geom.Mp, TAP_N)
+    Gb = torch.matmul(Qp[..., :c], bkv[:Cc].float().reshape(heads, c, 1)).squeeze(-1)                # (B, h, Mp)
+    tgeom = dc_replace(geom, N=N - split)
+    key_y = (pos[:, split:, 0].float() + 1.0) * (0.5 * (Hi - 1))
+    key_x = (pos[:, split:, 1].float() + 1.0) * (0.5 * (Wi - 1))
+    Rn, LSE_c = _TapAttn.apply(G, a[:, split:], b[:, split:], key_y, key_x, Tt, tgeom)
+    LSE_c = (LSE_c.reshape(B, V, heads, geom.Mp) + Gb[:, None]).reshape(Bp, heads, geom.Mp)
+    Vp = F.pad(kvp[..., Cc:].reshape(Bp, TAP_N, heads, c), (0, pad_c)).permute(0, 2, 1, 3)          # (B', h, 12, 32)
+    bv = F.pad(bkv[Cc:].float().reshape(1, heads, 1, c), (0, pad_c))
+    O_c = torch.matmul(Rn, Vp) + bv
+    if O_r is None:
+        return unpack_out(O_c, S, c)
+    LSE_t = torch.logaddexp2(LSE_r, LSE_c)
+    O = torch.exp2(LSE_r - LSE_t)[..., None] * O_r + torch.exp2(LSE_c - LSE_t)[..., None] * O_c
     return unpack_out(O, S, c)
+
+
+# --------------------------------------------------------------------------------------------------
+# tap kernels (csrc/attn_tap*.hip): the projector-pinned keys without K and V
+# --------------------------------------------------------------------------------------------------
+TAP_R, TAP_C, TAP_N, TAP_SLOTS = 4, 3, 12, 16     # csrc/attn_tap.h: feature rows 0..3 x columns 0..2, 16 operand slots
+TAP_HEADROOM = 64.0                               # binades between the static softmax reference and the logits' upper bound
+LN2 = 0.6931471805599453
+
+
+def _neg_big(ed):
+    """logit of a masked key / offset of a padding row in the 16-bit operand dtype (finite in it)."""
+    return -1.0e30 if ed == torch.bfloat16 else -30000.0
+
+
+def _set_offset(G16: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """slots 12, 13 of the packed operand <- hi, lo 16-bit parts of the row offset c; returns hi + lo (float): what the
+    kernels add to the row's logits."""
+    hi = c.to(G16.dtype)
+    lo = (c - hi.float()).to(G16.dtype)
+    G16[..., 12] = hi
+    G16[..., 13] = lo
+    return hi.float() + lo.float()
+
+
+class _TapAttn(torch.autograd.Function):
+    """Softmax over a key segment whose keys sample inside the top-left 4 x 3 feature pixels, in terms of the TAP
+    WEIGHTS instead of K and V (csrc/attn_tap.h):  logits S[n][q] = sum_t w_t(n) G[q][t] + bias[n][q]  ->
+        Rn[q][t] = sum_n softmax_n(S)[n][q] w_t(n)      (P, h, Mp, 12)
+        LSE[q]   = log2 sum_n 2^S[n][q]                 (P, h, Mp)
+    Both outputs are differentiable (the caller turns Rn into O = Rn Vpix + bv and merges LSE with the other key segment
+    of the same softmax in plain torch code).  G (P, h, Mp, 12) float: log2-domain logit per tap; key_a, key_b (P, N)
+    table coordinates, key_y, key_x (P, N) sampling positions in feature pixels; Tt the packed table (pack_table)."""
+
+    @staticmethod
+    def forward(ctx, G, key_a, key_b, key_y, key_x, Tt, geom: AttnGeom):
+        _require_gpu(G, key_a, key_b, key_y, key_x, Tt)
+        L = _lib.lib()
+        ed = _edtype(geom.precision)
+        dev = G.device
+        P, h, Mp = geom.n_prob, geom.heads, geom.Mp
+        d = geom.desc()
+        pad = geom.Np - geom.N
+        ka, kb, ky, kx = (F.pad(t.float(), (0, pad)).contiguous() for t in (key_a, key_b, key_y, key_x))
+        ws = torch.empty(L.bevr_attn_tap_ws_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
+        _lib.check(L.bevr_attn_tap_prep(C.byref(d), _ptr(ka), _ptr(kb), _ptr(ky), _ptr(kx), _ptr(ws), _stream()),
+                   "bevr_attn_tap_prep")
+        Ttc = Tt.contiguous()
+        pair = torch.stack((Ttc[..., :-1], Ttc[..., 1:]), dim=-1).contiguous()
+        G16 = torch.zeros(P, h, Mp, TAP_SLOTS, device=dev, dtype=ed)
+        G16[..., :TAP_N] = G
+        G16[..., 14] = _neg_big(ed)
+        # static softmax reference: an upper bound of the row's logits (the tap weights and the 4 bias taps are convex
+        # weights up to their 16-bit rounding) minus the headroom -- no weight can overflow, nothing is tracked in the loop
+        tmax = Ttc.amax((1, 2)).clamp_min(0.0)
+        ub = 1.01 * (G16[..., :TAP_N].float().amax(-1).clamp_min(0.0) + tmax[None, :, None]) + 0.01
+        mref = (-_set_offset(G16, TAP_HEADROOM - ub)).contiguous()
+        # zeros: the kernels work in 16-row blocks and never touch the rows past the last block of a column
+        R = torch.zeros(P, h, Mp, TAP_SLOTS, device=dev, dtype=torch.float32)
+        flags = torch.zeros(P * h, geom.S, device=dev, dtype=torch.int32)
+        _lib.check(KERNEL_TIMER.run("bevr_attn_tap_fwd", _attn_flops(geom, 2), L.bevr_attn_tap_fwd, C.byref(d), _ptr(G16),
+                                    _ptr(ws), _ptr(pair), _ptr(mref), _ptr(R), _ptr(flags), _stream()), "bevr_attn_tap_fwd")
+        # rows past the grid: Rn = 0, LSE = 0 (finite: the caller's merge with the other key segment stays finite there)
+        valid = (torch.arange(Mp, device=dev) % geom.Sp) < geom.S
+        l = torch.where(valid, R[..., 15], torch.ones_like(mref))
+        LSE = torch.where(valid, mref + torch.log2(l), torch.zeros_like(mref))
+        Rn = torch.where(valid[:, None], R[..., :TAP_N] / l[..., None], torch.zeros_like(R[..., :TAP_N]))
+        ctx.geom = geom
+        ctx.save_for_backward(G16, Rn, LSE, ws, pair, Ttc)
+        ctx.set_materialize_grads(False)
+        return Rn, LSE
+
+    @staticmethod
+    def backward(ctx, dRn, dLSE):
+        geom: AttnGeom = ctx.geom
+        G16, Rn, LSE, ws, pair, Ttc = ctx.saved_tensors
+        L = _lib.lib()
+        ed = G16.dtype
+        dev = G16.device
+        P, h, Mp = geom.n_prob, geom.heads, geom.Mp
+        d = geom.desc()
+        valid = (torch.arange(Mp, device=dev) % geom.Sp) < geom.S
+        H16 = torch.zeros(P, h, Mp, TAP_SLOTS, device=dev, dtype=ed)
+        if dRn is not None:
+            H16[..., :TAP_N] = dRn * LN2
+        # delta from the values the kernel contracts (the rounded H): dS = P (dP - delta) then cancels where P -> 1
+        delta = (Rn * H16[..., :TAP_N].float()).sum(-1)
+        if dLSE is not None:
+            delta = delta - dLSE
+        _set_offset(H16, -delta)
+        Gq = G16.clone()
+        _set_offset(Gq, torch.where(valid, -LSE, torch.full_like(LSE, _neg_big(ed))))
+        dG = torch.zeros(P, h, Mp, TAP_SLOTS, device=dev, dtype=torch.float32)     # rows past the last 16-row block: never written
+        dT = torch.zeros_like(Ttc)
+        _lib.check(KERNEL_TIMER.run("bevr_attn_tap_bwd_q", _attn_flops(geom, 3), L.bevr_attn_tap_bwd_q, C.byref(d), _ptr(Gq),
+                                    _ptr(H16), _ptr(ws), _ptr(pair), _ptr(dG), _ptr(dT), _stream()), "bevr_attn_tap_bwd_q")
+        dk = [torch.zeros(P, geom.Np, device=dev, dtype=torch.float32) for _ in range(4)]
+        _lib.check(KERNEL_TIMER.run("bevr_attn_tap_bwd_k", _attn_flops(geom, 4), L.bevr_attn_tap_bwd_k, C.byref(d), _ptr(Gq),
+                                    _ptr(H16), _ptr(ws), _ptr(Ttc), *[_ptr(t) for t in dk], _stream()), "bevr_attn_tap_bwd_k")
+        da, db, dy, dx = (t[:, :geom.N] for t in dk)
+        return dG[..., :TAP_N] * valid[:, None], da, db, dy, dx, dT, None
+
+
+def tap_supported(precision: int, groups: int) -> bool:
+    """BEVR_TAP=0 keeps the pinned keys on the cell kernels."""
+    return precision == _lib.PREC_BF16 and groups == 1 and os.environ.get("BEVR_TAP", "1") != "0"
 
 
 def kv_source_supported(C: int, heads: int, groups: int, precision: int) -> bool:

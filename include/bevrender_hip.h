@@ -244,7 +244,7 @@ int bevr_attn_tap_bwd_q(const bevr_attn_desc* d, const void* G, const void* H, c
 /* Key-side backward: the gradients of every key's table coordinates and sampling position (G, H as bevr_attn_tap_bwd_q),
  *   dkey_a, dkey_b, dkey_y, dkey_x [n_prob][Np] float, ACCUMULATED over the heads (caller zeroes them):
  *   d/d key_a, d/d key_b through the bias (bilinear derivative of the table), d/d key_y, d/d key_x through the tap
- *   weights -- both paths of it: the logits (G) and the values (H carries dO . Vpix).  Kinks as F.grid_sample's backward
+ *   weights -- both paths of it: the logits (G) and the values (sum_q P H / ln2: H carries ln2 dO . Vpix).  Kinks as F.grid_sample's backward
  *   (floor-based: the derivative of the tap pair the position sits between). */
 int bevr_attn_tap_bwd_k(const bevr_attn_desc* d, const void* G, const void* H, const void* tap_ws,
                         const float* table_pair, float* dkey_a, float* dkey_b, float* dkey_y, float* dkey_x, void* stream);

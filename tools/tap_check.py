@@ -77,7 +77,7 @@ def reference(G, Gb, a, b, ys, xs, T2, S, Wt, N, mimic=None):
 
 
 def grad_reference(G, Gb, H, Hc, a, b, ys, xs, T2, S, Wt, N, LSE):
-    """float64 gradients through autograd of a pseudo-loss: with P, dS held constant, L = sum dS S + sum P (w . H) has
+    """float64 gradients through autograd of a pseudo-loss: with P, dS held constant, L = sum dS S + sum P (w . H) / ln2 has
     dL/dG = sum_n w dS, dL/dT2 = the table gradient, and dL/d(a, b, ys, xs) = the key-side gradients (the second term
     is the path through V_n = sum_t w_t Vpix_t).  Returns dG (P, h, S(j), S(i), 16), dT2, da, db, dys, dxs."""
     P, h, Mp, _ = G.shape
@@ -99,7 +99,7 @@ def grad_reference(G, Gb, H, Hc, a, b, ys, xs, T2, S, Wt, N, LSE):
             dpl = torch.einsum("hit,nt->hin", Hd[p, :, j, :, :12], w[:, :12])
             dS = (Pm * (dpl + Hcd[p, :, j, :, None])).detach()
             dG[p, :, j] = torch.einsum("hin,nk->hik", dS, w.detach())
-            ((dS * lg).sum() + (Pm * dpl).sum()).backward(retain_graph=True)
+            ((dS * lg).sum() + (Pm * dpl).sum() * ops.LOG2E).backward(retain_graph=True)     # H carries ln2: the value path does not
     return dG, T2l.grad, al.grad, bl.grad, yl.grad, xl.grad
 
 
@@ -246,6 +246,9 @@ def check_case(name, **kw):
     Tt = ops.pack_table(T.float(), geom).contiguous()
     da, db, dy, dx = [t.double()[:, :geom.N] for t in run_bwd_k(geom, G, Gc, H, Hc, ws, Tt)]
     print(f"{'':28s} bwd_k: da {relerr(da, wda):.2e}  db {relerr(db, wdb):.2e}  dys {relerr(dy, wdy):.2e}  dxs {relerr(dx, wdx):.2e}")
+    out.update(flagged=int(flags.sum()), dG=relerr(dGg[..., :12], wdG[..., :12]), dGb=relerr(dGg[..., 15], wdG[..., 15]),
+               dtable=relerr(dTg, wdT), da=relerr(da, wda), db=relerr(db, wdb), dys=relerr(dy, wdy), dxs=relerr(dx, wdx),
+               dead=Rn_got[..., 14].abs().max().item())
     return out
 
 

@@ -54,17 +54,17 @@ def ring_rig(V, img_w, img_h):
 class LiftBlock(nn.Module):
     """L encoder layers + the correlation head: the unit the metric counts."""
 
-    def __init__(self, S, C, heads, D, V, L, img_w, img_h, precision, device):
+    def __init__(self, S, C, heads, D, V, L, img_w, img_h, precision, device, rig=None, bound=None):
         super().__init__()
         from bevrender_amd.model.bev_cmr_proj import BEV2CameraProjector
         from bevrender_amd.model.encoder import EncoderLayer
         from bevrender_amd.loss.contrastive_loss import ContrastiveLoss
         from bevrender_amd.loss.lift_loss import LiftedStructureLoss
-        T, K = ring_rig(V, img_w, img_h)
+        T, K = rig if rig is not None else ring_rig(V, img_w, img_h)
         proj = BEV2CameraProjector(imu_to_rgb={0: T}, K={0: K}, vehicle_type_code=0, img_width=img_w, img_height=img_h,
                                    ori_img_width=img_w, ori_img_height=img_h, device=device)
         self.layers = nn.ModuleList([
-            EncoderLayer(bev_bound={"X": 50, "Y": 50, "Z": 2}, bev2cmr_projector=proj, n_views=V, bev_feat_shape=S,
+            EncoderLayer(bev_bound=bound or {"X": 50, "Y": 50, "Z": 2}, bev2cmr_projector=proj, n_views=V, bev_feat_shape=S,
                          bev_depth_dim=D, z_shift=-1.0, dim_embed=C, expansion=4, stage_idx=0, n_groups=1,
                          n_heads=heads, stride=1, kernel_size=3, batch_size=1, scale_offset_range=True,
                          drop_path_rate=0.0, precision=precision) for _ in range(L)])
@@ -107,11 +107,20 @@ class LiftBlock(nn.Module):
         return corr + bev.square().mean()
 
 
-# algorithmic matrix products per (query, key) pair of each attention entry point: QK^T + PV forward; S, dP, dQ on the
-# query side; S, dP, dV, dK on the key side.  The cell kernels' bias / table-gradient products are extra work the
-# formulation spends, not algorithmic flops: they are not counted.
+# matrix products per (query, key) pair (2 * 32 flop each) that the flash-style formulation RUNS in each entry point:
+# QK^T + PV forward; S, dP, dQ on the query side; S, dP, dV, dK on the key side -- 9 per forward + backward.  This is what
+# ops.py attaches to a launch and what the per-kernel `roofline` lines price (the work a kernel of that kind does).
+# SURVEY.md 8d counts 7 (backward = 2.5 x forward: S is recomputed once, not twice): ALG_MATMUL splits the backward's 5
+# evenly between the two sides, and `all_attention_aggregate` is on that accounting, with the 9-product figure kept as
+# `executed`.  The tap / cell kernels' bias and table-gradient products are extra work their formulation spends, and
+# the tap kernels run FEWER matrix flops than these counts (contraction 12 taps instead of 32 channels): the counts
+# are the algorithm's, not the instruction stream's.
 N_MATMUL = {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4,
-            "bevr_attn_cell_fwd": 2, "bevr_attn_cell_bwd_q": 3, "bevr_attn_cell_bwd_k": 4}
+            "bevr_attn_cell_fwd": 2, "bevr_attn_cell_bwd_q": 3, "bevr_attn_cell_bwd_k": 4,
+            "bevr_attn_tap_fwd": 2, "bevr_attn_tap_bwd_q": 3, "bevr_attn_tap_bwd_k": 4}
+ALG_MATMUL = {k: (2.0 if k.endswith("fwd") else 2.5) for k in N_MATMUL}
+# SURVEY.md 8d, algorithmic HBM bytes per sample of the block (L = 2, T = 2): 374 MB + the correlation head's 82 MB
+BLOCK_HBM_BYTES_PER_SAMPLE = {4: 374e6, 8: 456e6}
 
 
 def csrc_sha():
@@ -241,14 +250,52 @@ def cpu_baseline(seconds_budget=12.0):
     return out
 
 
+def gpu_same_workloads(dev):
+    """The GPU path on the two workloads the CPU baseline times (nothing put the two on the SAME workload):
+    BASELINE config 1 exactly (1 camera, 16x16 features, 50x50 BEV, batch 2) and config 2's geometry at S = 56 (6-camera
+    ring, 64x176 features, batch 1), whole LiftBlock steps (L = 2, T = 2, correlation head, AdamW), bf16 operands and the
+    exact-f32 mode (the CPU baseline's arithmetic)."""
+    C, heads, D, L = 64, 2, 5, 2
+    T1 = np.eye(4); T1[:3, :3] = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], dtype=np.float64); T1[:3, 3] = (0, 0, 1.5)
+    K1 = np.array([[100, 0, 64, 0], [0, 100, 64, 0], [0, 0, 1, 0]], dtype=np.float64)
+    cases = {"cfg1": dict(S=50, V=1, img=(128, 128), feat=(16, 16), B=2, rig=([T1], [K1]), bound={"X": 20, "Y": 10, "Z": 2}),
+             "cfg2_geometry_s56": dict(S=56, V=6, img=(704, 256), feat=(64, 176), B=1, rig=None, bound=None)}
+    res = {}
+    for name, c in cases.items():
+        res[name] = {}
+        for mode in ("bf16", "f32"):
+            torch.manual_seed(15213)
+            m = LiftBlock(c["S"], C, heads, D, c["V"], L, c["img"][0], c["img"][1], mode, dev, rig=c["rig"], bound=c["bound"]).to(dev)
+            o = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+            f = [torch.randn(c["B"] * c["V"], C, *c["feat"], device=dev, dtype=torch.bfloat16)
+                 .contiguous(memory_format=torch.channels_last) for _ in range(2)]
+            me = torch.nn.functional.normalize(torch.randn(c["B"], C * c["S"] ** 2, device=dev), dim=1)
+
+            def st():
+                o.zero_grad(set_to_none=True)
+                m(f[0], f[1], me, 1).backward()
+                o.step()
+            st()
+            torch.cuda.synchronize()
+            n, t0 = 0, time.perf_counter()
+            while n < 3 or (time.perf_counter() - t0 < 1.0 and n < 50):
+                st()
+                n += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[name][mode] = {"samples_per_s": round(c["B"] * n / dt, 3), "steps": n, "batch": c["B"]}
+            del m, o
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU (8 = BASELINE config 3, 4 = config 2)")
-    ap.add_argument("--f32-steps", type=int, default=1,
-                    help="also time this many steps in the fp32-tolerance mode (split-bf16 products, bf16x3) and in the "
+    ap.add_argument("--f32-steps", type=int, default=5,
+                    help="also time this many steps in the fp32-tolerance mode (split-bf16 products, bf16x3) and one in the "
                          "exact-f32 MFMA mode (rank 0, N=1; 0 = skip)")
     ap.add_argument("--bev", type=int, default=200, help="BEV side (200 = BASELINE config; smaller for debugging)")
     ap.add_argument("--frames", type=int, default=2, help="temporal frames T: T - 1 no-grad history frames + the current one")
@@ -333,11 +380,11 @@ def main():
         dom = max(attn, key=lambda k: attn[k]["ms"]) if attn else None
         roof = None
         # HBM bytes per launch: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command (separate
-        # passes, gfx950 correction applied) by tools/measure_traffic.sh, which writes profiles/r03_traffic.json together
+        # passes, gfx950 correction applied) by tools/measure_traffic.sh, which writes profiles/r04_traffic.json together
         # with the kernel sources' sha; only attached when that file was measured at this batch / BEV side / precision
         # AND on these very kernel sources (a stale file is not reported as measured traffic: ADVICE r02)
-        traffic_db, traffic_note = {}, "no profiles/r03_traffic.json for this batch / BEV side / precision"
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        traffic_db, traffic_note = {}, "no profiles/r04_traffic.json for this batch / BEV side / precision"
+        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
@@ -345,7 +392,7 @@ def main():
                 if tj.get("csrc_sha") == csrc_sha():
                     traffic_db, traffic_note = tj["kernels"], f"measured at csrc_sha {tj.get('csrc_sha')}"
                 else:
-                    traffic_note = (f"profiles/r03_traffic.json was measured at csrc_sha {tj.get('csrc_sha')}, the kernels "
+                    traffic_note = (f"profiles/r04_traffic.json was measured at csrc_sha {tj.get('csrc_sha')}, the kernels "
                                     f"are at {csrc_sha()}: not attached")
         if dom:
             rec = attn[dom]
@@ -362,11 +409,23 @@ def main():
                     "all_attention": {k: {"avg_ms": round(v["ms"] / v["n"], 3),
                                           "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak, 5)}
                                       for k, v in sorted(attn.items())}}
-            # every attention launch of the timed region together: algorithmic flops / summed kernel time
-            tot_f, tot_ms = sum(v["flops"] for v in attn.values()), sum(v["ms"] for v in attn.values())
-            roof["all_attention_aggregate"] = {"achieved": round(tot_f / (tot_ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
-                                               "frac": round(tot_f / (tot_ms * 1e-3) / 1e12 / peak, 5),
+            # every attention launch of the timed region together, on SURVEY 8d's accounting (7 products per pair forward +
+            # backward); `executed`: the 9 products the two-sided backward runs (S and dP on both sides)
+            tot_ms = sum(v["ms"] for v in attn.values())
+            tot_exec = sum(v["flops"] for v in attn.values())
+            tot_alg = sum(v["flops"] / N_MATMUL[k] * ALG_MATMUL[k] for k, v in attn.items())
+            roof["all_attention_aggregate"] = {"achieved": round(tot_alg / (tot_ms * 1e-3) / 1e12, 3), "unit": "TFLOP/s",
+                                               "frac": round(tot_alg / (tot_ms * 1e-3) / 1e12 / peak, 5),
+                                               "accounting": "SURVEY 8d: 2 products per pair forward, 5 backward",
+                                               "executed": {"achieved": round(tot_exec / (tot_ms * 1e-3) / 1e12, 3),
+                                                            "frac": round(tot_exec / (tot_ms * 1e-3) / 1e12 / peak, 5)},
                                                "ms_per_step": round(tot_ms / args.steps, 2)}
+            # per call: TSA (square table) and SCA (the scattered keys on the region kernels, the pinned ones on the tap
+            # kernels) separately -- kernel_ms_per_step lumps them
+            roof["kernel_ms_per_step_by_call"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 2), "launches": v["n"],
+                                                      "avg_ms": round(v["ms"] / v["n"], 3),
+                                                      "Tpairs_per_s": round(v["flops"] / (2.0 * 32 * N_MATMUL[k.split("[")[0]]) / (v["ms"] * 1e-3) / 1e12, 3)}
+                                                  for k, v in sorted(ops.KERNEL_TIMER.by_tag.items()) if k.startswith("bevr_attn")}
         # What actually paces the attention kernels is per-pair work on the LDS pipe (bias taps, per-key constants, the
         # table-gradient atomics), not the matrix cores.  Secondary, clearly separate from
         # `roofline`: the pair rate against the rate at which one CU's LDS pipe could issue each kernel's LDS
@@ -415,12 +474,20 @@ def main():
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             "roofline": roof, "roofline_hbm": roof_hbm, "roofline_lds": roof_lds,
         }
+        if (S, args.frames, args.img) == (200, 2, "704x256") and B in BLOCK_HBM_BYTES_PER_SAMPLE:
+            # the block as a whole against HBM (north_star / SURVEY 8d): algorithmic bytes per sample x samples/s.  Small by
+            # construction: the block is compute-bound (arithmetic intensity ~1.6e5 flop/B)
+            gbs = BLOCK_HBM_BYTES_PER_SAMPLE[B] * (total_samples / dt) / world / 1e9
+            out["roofline_hbm_block"] = {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": round(gbs / HBM_PEAK_GBS, 6),
+                                         "bytes_per_sample": BLOCK_HBM_BYTES_PER_SAMPLE[B],
+                                         "note": "whole block per GPU, SURVEY 8d's algorithmic bytes; compute-bound, so small"}
         if world == 1 and args.f32_steps > 0 and args.precision == "bf16":
             # the reference's arithmetic is fp32: the same workload in the kernels' exact-f32 MFMA mode, as a secondary
             # figure (never `value`)
             del net, opt, model
 
-            def timed_mode(mode):
+            def timed_mode(mode, n_steps):
                 torch.cuda.empty_cache()
                 torch.manual_seed(15213 + rank)
                 m32 = LiftBlock(S, C, heads, D, V, L, img_w, img_h, mode, dev).to(dev)
@@ -432,20 +499,43 @@ def main():
                     o32.step()
                 step32()
                 torch.cuda.synchronize()
+                ops.KERNEL_TIMER.start()
                 t1 = time.perf_counter()
-                for _ in range(args.f32_steps):
+                for _ in range(n_steps):
                     step32()
                 torch.cuda.synchronize()
                 d32 = time.perf_counter() - t1
-                return {"value": round(B * args.f32_steps / d32, 4), "unit": "samples/s", "steps": args.f32_steps,
-                        "warmup": 1, "ms_per_step": round(d32 / args.f32_steps * 1e3, 2)}
-            out["f32_mode"] = dict(timed_mode("bf16x3"), note="same workload at fp32 tolerance: f32 storage and per-pair "
-                                   "arithmetic, matrix products as three split-bf16 MFMAs (BEVR_PREC_BF16X3; results within "
-                                   "~1e-5 of the exact mode, tests hold it to the f32 limits)")
-            out["f32_exact_mode"] = dict(timed_mode("f32"), note="exact-f32 MFMA operands (v_mfma_f32_32x32x2_f32), the "
-                                         "tests' reference mode")
+                kt = {k: v for k, v in ops.KERNEL_TIMER.stop().items() if k.startswith("bevr_attn")}
+                res = {"value": round(B * n_steps / d32, 4), "unit": "samples/s", "steps": n_steps,
+                       "warmup": 1, "ms_per_step": round(d32 / n_steps * 1e3, 2)}
+                if kt:   # the dominant kernel of this mode against this mode's matrix peak
+                    dk = max(kt, key=lambda k: kt[k]["ms"])
+                    pk = MFMA_PEAK_TFLOPS[mode]
+                    ach = kt[dk]["flops"] / (kt[dk]["ms"] * 1e-3) / 1e12
+                    tms = sum(v["ms"] for v in kt.values())
+                    talg = sum(v["flops"] / N_MATMUL[k] * ALG_MATMUL[k] for k, v in kt.items())
+                    res["roofline"] = {"bound": "mfma", "kernel": dk, "achieved": round(ach, 3), "peak": round(pk, 1),
+                                       "unit": "TFLOP/s", "frac": round(ach / pk, 5), "avg_ms": round(kt[dk]["ms"] / kt[dk]["n"], 3),
+                                       "launches": kt[dk]["n"],
+                                       "all_attention_aggregate_frac": round(talg / (tms * 1e-3) / 1e12 / pk, 5)}
+                return res
+            # `f32_mode` stays the exact-f32 figure (comparable with rounds 1-2); the split mode has its own key
+            out["bf16x3_mode"] = dict(timed_mode("bf16x3", args.f32_steps), note="same workload at fp32 TOLERANCE: f32 "
+                                      "storage and per-pair arithmetic, matrix products as three split-bf16 MFMAs "
+                                      "(BEVR_PREC_BF16X3; results within ~1e-5 of the exact mode, tests hold it to the f32 "
+                                      "limits); peak = bf16 dense / 3")
+            out["f32_mode"] = dict(timed_mode("f32", 1), note="exact-f32 MFMA operands (v_mfma_f32_32x32x2_f32), the "
+                                   "tests' reference mode and the reference's arithmetic; peak = the f32 matrix rate")
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (bench contract)
+            torch.cuda.empty_cache()
+            same = gpu_same_workloads(dev)
             out["cpu_baseline"] = cpu_baseline()
+            # the GPU path on the SAME two workloads (whole steps incl. correlation head and AdamW; the CPU figures are
+            # the encoder layers alone), f32 = the kernels' exact-f32 mode, the CPU baseline's arithmetic
+            out["cpu_baseline"]["gpu_same_workload"] = {
+                "cfg1": dict(same["cfg1"], cpu_samples_per_s=round(out["cpu_baseline"]["value"], 4)),
+                "cfg2_geometry_s56": dict(same["cfg2_geometry_s56"], cpu_samples_per_s=round(
+                    out["cpu_baseline"]["cfg2_geometry_s56"]["samples_per_s_at_s56"], 5))}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

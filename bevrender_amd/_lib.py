@@ -20,7 +20,7 @@ LIB_PATH = os.environ.get("BEVRENDER_LIB") or os.path.join(_HERE, "lib", "libbev
 CSRC = os.path.join(_HERE, "csrc")
 
 PREC_F32, PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2, 3
-ABI_VERSION = 3   # BEVR_ABI_VERSION of include/bevrender_hip.h this binding was written against
+ABI_VERSION = 4   # BEVR_ABI_VERSION of include/bevrender_hip.h this binding was written against
 
 # every symbol include/bevrender_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -22,7 +22,11 @@
 
 namespace {
 
+#if BEVR_VARIANT == 8
+constexpr int NKW = 9;                 // key waves per workgroup
+#else
 constexpr int NKW = 7;                 // key waves per workgroup
+#endif
 constexpr int NCW = 8;                 // table columns of the shared window (a chunk is 4 wide: origins may differ by 4 columns ...
 constexpr int NRX = 8;                 // ... and by 8 rows inside one workgroup)
 struct LdsK {
@@ -45,7 +49,7 @@ __device__ __forceinline__ bool tile_fits(const StepBox& sb, float jrx, int a0w,
 // workgroup without any leaves at once: every workgroup of a cell-sorted segment).  Two launches: with both bodies in one
 // loop the matrix path reloaded loop invariants from scratch on every slab.
 template <int PREC, bool SLOW>
-__global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
+__global__ __launch_bounds__(64 * (NKW + 1), (NKW == 9 ? 5 : 4)) void attn_tap_bwd_k_kernel(
     bevr_attn_desc d, const char* __restrict__ G, const char* __restrict__ H, const char* __restrict__ tap_ws,
     const float* __restrict__ table_t, float* __restrict__ dkey_a, float* __restrict__ dkey_b,
     float* __restrict__ dkey_y, float* __restrict__ dkey_x, int n_wg_ph) {
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
   // and its position gradient through the matrix cores); else the per-pair gather from the table in global memory
   auto slab = [&](auto fit_tag, const char* base, int i0) {
     constexpr bool FIT = decltype(fit_tag)::value;
-    const bool two = i0 + 16 < d.S;                 // the slab's second row block holds real rows (uniform)
+    // (rows past the grid carry the offset -big in G: their weights are 0 without a test here)
     bf16x8 qa[2], ha[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
           const float t00 = c0p[0], t01 = c0p[1], t10 = c0p[HpT], t11 = c0p[HpT + 1];
           const float u0 = t00 + fy * (t01 - t00), u1 = t10 + fy * (t11 - t10);
           const float sv = (r < 4 ? s0[r & 3] : s1[r & 3]) + (dead ? 0.f : u0 + fx * (u1 - u0));
-          p[r] = (r < 4 || two) ? fast_exp2(sv) : 0.f;
+          p[r] = fast_exp2(sv);
           ds[r] = p[r] * (r < 4 ? q0[r & 3] : q1[r & 3]);
           pa += ds[r] * ((1.0f - fx) * (t01 - t00) + fx * (t11 - t10));
           pb += ds[r] * (u1 - u0);
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(512, 4) void attn_tap_bwd_k_kernel(
         for (int r = 0; r < 4; ++r) {
           p[r] = fast_exp2(s0[r]);
           ds[r] = p[r] * q0[r];
-          p[4 + r] = two ? fast_exp2(s1[r]) : 0.f;
+          p[4 + r] = fast_exp2(s1[r]);
           ds[4 + r] = p[4 + r] * q1[r];
         }
       }

@@ -220,6 +220,7 @@ class _KernelTimer:
     def __init__(self):
         self.on = False
         self.records = []
+        self.by_tag = {}
 
     def start(self):
         self.on, self.records = True, []
@@ -228,27 +229,29 @@ class _KernelTimer:
         self.on = False
         torch.cuda.synchronize()
         out = {}
-        for name, flops, nbytes, e0, e1 in self.records:
-            r = out.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "max_ms": 0.0})
+        self.by_tag = {}
+        for name, flops, nbytes, e0, e1, tag in self.records:
             ms = e0.elapsed_time(e1)
-            r["ms"] += ms
-            r["max_ms"] = max(r["max_ms"], ms)
-            r["n"] += 1
-            r["flops"] += flops
-            r["bytes"] += nbytes
+            for key, dst in ((name, out), (f"{name}[{tag}]", self.by_tag)):
+                r = dst.setdefault(key, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0, "max_ms": 0.0})
+                r["ms"] += ms
+                r["max_ms"] = max(r["max_ms"], ms)
+                r["n"] += 1
+                r["flops"] += flops
+                r["bytes"] += nbytes
         self.records = []
         return out
 
-    def run(self, name, flops, fn, *args, nbytes=0.0):
-        """flops / nbytes: the launch's ALGORITHMIC work (MFMA flops of an attention launch; HBM bytes of a sampling
-        launch), for the roofline lines of bench.py."""
+    def run(self, name, flops, fn, *args, nbytes=0.0, tag=""):
+        """flops / nbytes: the launch's work (matrix flops of an attention launch, 2 * 32 per pair and product it runs;
+        HBM bytes of a sampling launch), for the roofline lines of bench.py.  tag: which call (bench.py's per-call split)."""
         if not self.on:
             return fn(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)
         e1.record()
-        self.records.append((name, flops, nbytes, e0, e1))
+        self.records.append((name, flops, nbytes, e0, e1, tag))
         return rc
 
 
@@ -297,6 +300,11 @@ def _attn_flops(geom, n_matmul, n_keys=None):
     """algorithmic MFMA flops of one attention launch: 2 flop/MAC x head_dim 32 x query-key pairs."""
     n = geom.N if n_keys is None else n_keys
     return 2.0 * HEAD_DIM * geom.n_prob * geom.heads * (geom.S * geom.S) * n * n_matmul
+
+
+def _call_tag(geom) -> str:
+    """which attention call a launch belongs to: TSA's table is square (2S - 1 wide), SCA's 2 S D - 1 wide."""
+    return ("tsa" if geom.Wt == 2 * geom.S - 1 else "sca") + f",N={geom.N}"
 
 
 def cell_order(a: torch.Tensor, b: torch.Tensor, n_tail: int = 0) -> torch.Tensor:
@@ -417,11 +425,11 @@ class _AttnCore(torch.autograd.Function):
                 l_in = _ptr(LSE) if i > 0 else None
                 _lib.check(KERNEL_TIMER.run("bevr_attn_cell_fwd", _attn_flops(g, 2), L.bevr_attn_cell_fwd, C.byref(d),
                                             _ptr(Qe), _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), o_in, l_in, _ptr(O),
-                                            _ptr(LSE), _stream()), "bevr_attn_cell_fwd")
+                                            _ptr(LSE), _stream(), tag=_call_tag(g)), "bevr_attn_cell_fwd")
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_fwd", _attn_flops(g, 2), L.bevr_attn_fwd, C.byref(d), _ptr(Qe),
                                             _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O), _ptr(LSE),
-                                            _stream()), "bevr_attn_fwd")
+                                            _stream(), tag=_call_tag(g)), "bevr_attn_fwd")
             saved += [Ke, Ve, Kt, ka, kb, key_ws]
         ctx.geom = geom
         # split mode: the packed V is not readable as numbers; the norm bound of the backward's scales from the rows
@@ -512,13 +520,13 @@ class _AttnCore(torch.autograd.Function):
             if sg.cell:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_cell_bwd_q", _attn_flops(g, 3), L.bevr_attn_cell_bwd_q, C.byref(d),
                                             _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
-                                            _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream()),
-                           "bevr_attn_cell_bwd_q")
+                                            _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream(),
+                                            tag=_call_tag(g)), "bevr_attn_cell_bwd_q")
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(g, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
                                             _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
-                                            _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream()),
-                           "bevr_attn_bwd_q")
+                                            _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream(),
+                                            tag=_call_tag(g)), "bevr_attn_bwd_q")
             del Kt
             dK = torch.empty(g.n_prob, g.heads, g.Np, HEAD_DIM, device=dev, dtype=torch.float32)
             dV = torch.empty_like(dK)
@@ -528,12 +536,12 @@ class _AttnCore(torch.autograd.Function):
                 _lib.check(KERNEL_TIMER.run("bevr_attn_cell_bwd_k", _attn_flops(g, 4), L.bevr_attn_cell_bwd_k, C.byref(d),
                                             _ptr(Qe), _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
                                             _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dK), _ptr(dV),
-                                            _ptr(da), _ptr(db), _stream()), "bevr_attn_cell_bwd_k")
+                                            _ptr(da), _ptr(db), _stream(), tag=_call_tag(g)), "bevr_attn_cell_bwd_k")
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_k", _attn_flops(g, 4), L.bevr_attn_bwd_k, C.byref(d), _ptr(Qe),
                                             _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(ka), _ptr(kb), _ptr(pair), _ptr(dOe),
                                             _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dK), _ptr(dV),
-                                            _ptr(da), _ptr(db), _stream()), "bevr_attn_bwd_k")
+                                            _ptr(da), _ptr(db), _stream(), tag=_call_tag(g)), "bevr_attn_bwd_k")
             # gradients of the row layout back to K | V rows (the adjoint of the packing), into the segment's rows
             kp = dkv.data_ptr() + sg.n0 * C2 * 4
             _lib.check(L.bevr_unpack_dkv(_ptr(dK), _ptr(dV), C.c_void_p(kp), C.c_void_p(kp + 2 * C2), C2, N, g.n_prob,
@@ -719,7 +727,7 @@ class _TapAttn(torch.autograd.Function):
         R = torch.zeros(P, h, Mp, TAP_SLOTS, device=dev, dtype=torch.float32)
         flags = torch.zeros(P * h, geom.S, device=dev, dtype=torch.int32)
         _lib.check(KERNEL_TIMER.run("bevr_attn_tap_fwd", _attn_flops(geom, 2), L.bevr_attn_tap_fwd, C.byref(d), _ptr(G16),
-                                    _ptr(ws), _ptr(pair), _ptr(mref), _ptr(R), _ptr(flags), _stream()), "bevr_attn_tap_fwd")
+                                    _ptr(ws), _ptr(pair), _ptr(mref), _ptr(R), _ptr(flags), _stream(), tag=_call_tag(geom)), "bevr_attn_tap_fwd")
         # rows past the grid: Rn = 0, LSE = 0 (finite: the caller's merge with the other key segment stays finite there)
         valid = (torch.arange(Mp, device=dev) % geom.Sp) < geom.S
         l = torch.where(valid, R[..., 15], torch.ones_like(mref))
@@ -753,10 +761,10 @@ class _TapAttn(torch.autograd.Function):
         dG = torch.zeros(P, h, Mp, TAP_SLOTS, device=dev, dtype=torch.float32)     # rows past the last 16-row block: never written
         dT = torch.zeros_like(Ttc)
         _lib.check(KERNEL_TIMER.run("bevr_attn_tap_bwd_q", _attn_flops(geom, 3), L.bevr_attn_tap_bwd_q, C.byref(d), _ptr(Gq),
-                                    _ptr(H16), _ptr(ws), _ptr(pair), _ptr(dG), _ptr(dT), _stream()), "bevr_attn_tap_bwd_q")
+                                    _ptr(H16), _ptr(ws), _ptr(pair), _ptr(dG), _ptr(dT), _stream(), tag=_call_tag(geom)), "bevr_attn_tap_bwd_q")
         dk = [torch.zeros(P, geom.Np, device=dev, dtype=torch.float32) for _ in range(4)]
         _lib.check(KERNEL_TIMER.run("bevr_attn_tap_bwd_k", _attn_flops(geom, 4), L.bevr_attn_tap_bwd_k, C.byref(d), _ptr(Gq),
-                                    _ptr(H16), _ptr(ws), _ptr(Ttc), *[_ptr(t) for t in dk], _stream()), "bevr_attn_tap_bwd_k")
+                                    _ptr(H16), _ptr(ws), _ptr(Ttc), *[_ptr(t) for t in dk], _stream(), tag=_call_tag(geom)), "bevr_attn_tap_bwd_k")
         da, db, dy, dx = (t[:, :geom.N] for t in dk)
         return dG[..., :TAP_N] * valid[:, None], da, db, dy, dx, dT, None
 

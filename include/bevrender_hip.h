@@ -43,7 +43,8 @@ extern "C" {
 /* 3: bevr_attn_fwd writes TWO LSE planes (round 2 changed that under version 2: a version-2 caller's [n_prob][heads][Mp]
  *    buffer is too small), the key workspace carries group boxes, bevr_attn_bwd_q takes grad_scale; new: bevr_attn_cell_*,
  *    problem strides of bevr_pack_kv / bevr_unpack_dkv, BEVR_PREC_F16, grad_scale[8] for every backward entry point. */
-#define BEVR_ABI_VERSION 3
+/* 4: new entry points bevr_attn_tap_* (the projector-pinned keys without K / V); nothing else changed. */
+#define BEVR_ABI_VERSION 4
 
 enum {
   BEVR_OK = 0,

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
     const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const char* __restrict__ dOt,
     const float* __restrict__ LSE, const float* __restrict__ delta, const float* __restrict__ grad_scale,
-    float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
+    float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dkey_a, float* __restrict__ dkey_b BEVR_DROP_PARAMS) {
   // NT 32-query tiles are staged and processed per barrier.  With one tile per barrier the three waves of a SIMD
   // ran in lockstep -- MFMAs together, then the VALU-bound bias / exp / gradient loop together, then the barrier --
   // and each pipe idled while the other worked; with two, the waves drift apart inside an iteration and one wave's
@@ -377,6 +377,19 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
         }
         dp = mma_frag(dof, vf[w], dp);   // dP[q][key] - delta[q]
       }
+#if BEVR_DROP
+      // dropout: dS = P (D dP - delta), dV from D P  (D = keep / (1 - p), the forward's mask: bevr_drop_keep)
+      unsigned kmask = 0u;
+      const float ksc = 65536.0f / (65536.0f - (float)drop_thr);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t hrow = bevr_drop_row(drop_seed, (uint32_t)ph, (uint32_t)(j * d.Sp + rb * 32 + crow(r, hi)));
+        const bool keep = bevr_drop_keep(hrow, (uint32_t)key[w], drop_thr);
+        const float nd = rc[NT * 8 + 2 * (r >> 2) + hi][r & 3];
+        dp[r] = keep ? fmaf(ksc, dp[r] - nd, nd) : nd;
+        kmask |= (keep ? 1u : 0u) << r;
+      }
+#endif
       PROF_TD(t2, s[0] + dp[15]);
       PROF_ADD(1, t2 - t1);
 
@@ -420,6 +433,10 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
       const float sa = sa2[0] + sa2[1], sb = sb2[0] + sb2[1];
       da[w] += sa;
       db[w] += sb;
+#if BEVR_DROP
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = ((kmask >> r) & 1u) ? s[r] * ksc : 0.f;
+#endif
       PROF_TD(t3, sa + sb + s[15]);
       PROF_ADD(2, t3 - t2);
       {
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
     const char* __restrict__ V, const float* __restrict__ key_a, const float* __restrict__ key_b,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const char* __restrict__ dOt,
     const float* __restrict__ LSE, const float* __restrict__ delta, const float* __restrict__ grad_scale,
-    float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dkey_a, float* __restrict__ dkey_b) {
+    float* __restrict__ dK, float* __restrict__ dV, float* __restrict__ dkey_a, float* __restrict__ dkey_b BEVR_DROP_PARAMS) {
   typedef LdsK<PREC> L;
   const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
   const float ds_inv = PREC == BEVR_PREC_F16 ? grad_scale[4] : 1.f, p_inv = PREC == BEVR_PREC_F16 ? grad_scale[5] : 1.f;
@@ -618,6 +635,18 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
       }
       s = mma_frag(qf, kf[w], s);      // S[q][key] - LSE[q]
       dp = mma_frag(dof, vf[w], dp);   // dP[q][key] - delta[q]
+#if BEVR_DROP
+      unsigned kmask = 0u;
+      const float ksc = 65536.0f / (65536.0f - (float)drop_thr);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t hrow = bevr_drop_row(drop_seed, (uint32_t)ph, (uint32_t)(j * d.Sp + i0 + crow(r, hi)));
+        const bool keep = bevr_drop_keep(hrow, (uint32_t)key_idx[w], drop_thr);
+        const float nd = rc[8 + 2 * (r >> 2) + hi][r & 3];
+        dp[r] = keep ? fmaf(ksc, dp[r] - nd, nd) : nd;
+        kmask |= (keep ? 1u : 0u) << r;
+      }
+#endif
 
       const KeyC c = kc[w];
       float tx = jr + c.b;
@@ -643,6 +672,10 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
       }
       da[w] += sa;
       db[w] += sb;
+#if BEVR_DROP
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = ((kmask >> r) & 1u) ? s[r] * ksc : 0.f;
+#endif
       dv[w] = mma_acc_b(dotf, s, dv[w]);
       dk[w] = mma_acc_b(qtf, dp, dk[w]);
     }
@@ -678,27 +711,36 @@ __global__ __launch_bounds__(TG) void attn_bwd_k_gather_kernel(
 template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* Qt, const void* K, const void* V, const float* key_a,
            const float* key_b, const float* table_pair, const void* dO, const void* dOt, const float* LSE,
-           const float* delta, const float* gs, float* dK, float* dV, float* dka, float* dkb, hipStream_t st) {
+           const float* delta, const float* gs, float* dK, float* dV, float* dka, float* dkb, hipStream_t st BEVR_DROP_PARAMS) {
   const int n_kb = (d.Np + KEYS_WG - 1) / KEYS_WG;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_kb;
   hipLaunchKernelGGL((attn_bwd_k_win_kernel<PREC>), dim3(grid), dim3(TW), 0, st, d, (const char*)Q, (const char*)Qt,
                      (const char*)K, (const char*)V, key_a, key_b, (const char*)table_pair, (const char*)dO,
-                     (const char*)dOt, LSE, delta, gs, dK, dV, dka, dkb);
+                     (const char*)dOt, LSE, delta, gs, dK, dV, dka, dkb BEVR_DROP_ARGS);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   hipLaunchKernelGGL((attn_bwd_k_gather_kernel<PREC>), dim3(grid * GSPLIT), dim3(TG), 0, st, d, (const char*)Q,
                      (const char*)Qt, (const char*)K, (const char*)V, key_a, key_b, (const char*)table_pair,
-                     (const char*)dO, (const char*)dOt, LSE, delta, gs, dK, dV, dka, dkb);
+                     (const char*)dO, (const char*)dOt, LSE, delta, gs, dK, dV, dka, dkb BEVR_DROP_ARGS);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
+#if BEVR_DROP
+extern "C" int bevr_attn_bwd_k_dropout(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
+                                       const float* key_a, const float* key_b, const float* table_pair, const void* dO,
+                                       const void* dOt, const float* LSE, const float* delta, const float* grad_scale,
+                                       float* dK, float* dV, float* dkey_a, float* dkey_b, unsigned drop_thr,
+                                       unsigned drop_seed, void* stream) {
+  if (drop_thr >= 65536u) return BEVR_E_SHAPE;
+#else
 extern "C" int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
                                const float* key_a, const float* key_b, const float* table_pair, const void* dO,
                                const void* dOt, const float* LSE, const float* delta, const float* grad_scale,
                                float* dK, float* dV, float* dkey_a, float* dkey_b, void* stream) {
+#endif
   int rc = bevr_check_desc(d);
   if (rc) return rc;
   if (!Q || !Qt || !K || !V || !key_a || !key_b || !table_pair || !dO || !dOt || !LSE || !delta || !dK || !dV ||
@@ -710,13 +752,13 @@ extern "C" int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const voi
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
     return launch<BEVR_PREC_BF16>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
-                                  dkey_a, dkey_b, st);
+                                  dkey_a, dkey_b, st BEVR_DROP_ARGS);
   if (d->precision == BEVR_PREC_F16)
     return launch<BEVR_PREC_F16>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
-                                 dkey_a, dkey_b, st);
+                                 dkey_a, dkey_b, st BEVR_DROP_ARGS);
   if (d->precision == BEVR_PREC_BF16X3)
     return launch<BEVR_PREC_BF16X3>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
-                               dkey_a, dkey_b, st);
+                               dkey_a, dkey_b, st BEVR_DROP_ARGS);
   return launch<BEVR_PREC_F32>(*d, Q, Qt, K, V, key_a, key_b, table_pair, dO, dOt, LSE, delta, grad_scale, dK, dV,
-                               dkey_a, dkey_b, st);
+                               dkey_a, dkey_b, st BEVR_DROP_ARGS);
 }

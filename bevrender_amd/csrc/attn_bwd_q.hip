@@ -116,7 +116,7 @@ __global__ __launch_bounds__(TQ, is16(PREC) ? 4 : 2) void attn_bwd_q_kernel(
     const char* __restrict__ V, const char* __restrict__ key_ws,
     const char* __restrict__ table_pair, const char* __restrict__ dO, const float* __restrict__ LSE,
     const float* __restrict__ delta, const float* __restrict__ grad_scale, float* __restrict__ dQ,
-    float* __restrict__ dtable) {
+    float* __restrict__ dtable BEVR_DROP_PARAMS) {
   typedef LdsQ<PREC> L;
   constexpr int EB = L::EB;
   constexpr int CAP = L::CAP;
@@ -475,6 +475,16 @@ __global__ __launch_bounds__(TQ, is16(PREC) ? 4 : 2) void attn_bwd_q_kernel(
             dp = mma_frag(vkf, dof, dp);
           }
         }
+#if BEVR_DROP
+        {
+          // dropout: O = sum_n D_n P_n V_n, D = keep / (1 - p)  =>  dS = P (D dP - delta); dp holds dP - delta
+          const uint32_t hrow = bevr_drop_row(drop_seed, (uint32_t)ph, (uint32_t)mq);
+          const float ksc = 65536.0f / (65536.0f - (float)drop_thr), nd2 = -dlt;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dp[r] = bevr_drop_keep(hrow, (uint32_t)(step * KT + kh * 32 + crow(r, hi)), drop_thr) ? fmaf(ksc, dp[r] - nd2, nd2) : nd2;
+        }
+#endif
         PROF_TD(t2, s[0] + dp[15]);
         PROF_ADD(1, t2 - tq);
 
@@ -593,6 +603,16 @@ __global__ __launch_bounds__(TQ, is16(PREC) ? 4 : 2) void attn_bwd_q_kernel(
           s = mma_frag(kf, qf, s);
           dp = mma_frag(vkf, dof, dp);
         }
+#if BEVR_DROP
+        {
+          // dropout: O = sum_n D_n P_n V_n, D = keep / (1 - p)  =>  dS = P (D dP - delta); dp holds dP - delta
+          const uint32_t hrow = bevr_drop_row(drop_seed, (uint32_t)ph, (uint32_t)mq);
+          const float ksc = 65536.0f / (65536.0f - (float)drop_thr), nd2 = -dlt;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dp[r] = bevr_drop_keep(hrow, (uint32_t)(step * KT + kh * 32 + crow(r, hi)), drop_thr) ? fmaf(ksc, dp[r] - nd2, nd2) : nd2;
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const KeyW c = kc[crow(r, hi)];
@@ -655,22 +675,30 @@ __global__ __launch_bounds__(TQ, is16(PREC) ? 4 : 2) void attn_bwd_q_kernel(
 template <int PREC>
 int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt, const void* V, const void* key_ws,
            const float* table_pair, const void* dO, const float* LSE, const float* delta,
-           const float* grad_scale, float* dQ, float* dtable, hipStream_t st) {
+           const float* grad_scale, float* dQ, float* dtable, hipStream_t st BEVR_DROP_PARAMS) {
   const int n_rb = (d.S + QROWS - 1) / QROWS, n_cb = (d.S + NCOL - 1) / NCOL;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_rb * n_cb;
   hipLaunchKernelGGL((attn_bwd_q_kernel<PREC>), dim3(grid), dim3(TQ), 0, st, d, (const char*)Q, (const char*)K,
                      (const char*)Kt, (const char*)V, (const char*)key_ws, (const char*)table_pair, (const char*)dO, LSE,
-                     delta, grad_scale, dQ, dtable);
+                     delta, grad_scale, dQ, dtable BEVR_DROP_ARGS);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
+#if BEVR_DROP
+extern "C" int bevr_attn_bwd_q_dropout(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
+                                       const void* key_ws, const float* table_pair, const void* dO,
+                                       const float* LSE, const float* delta, const float* grad_scale, float* dQ,
+                                       float* dtable, unsigned drop_thr, unsigned drop_seed, void* stream) {
+  if (drop_thr >= 65536u) return BEVR_E_SHAPE;
+#else
 extern "C" int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
                                const void* key_ws, const float* table_pair, const void* dO,
                                const float* LSE, const float* delta, const float* grad_scale, float* dQ,
                                float* dtable, void* stream) {
+#endif
   int rc = bevr_check_desc(d);
   if (rc) return rc;
   if (!Q || !K || !Kt || !V || !key_ws || !table_pair || !dO || !LSE || !delta || !grad_scale || !dQ ||
@@ -682,10 +710,10 @@ extern "C" int bevr_attn_bwd_q(const bevr_attn_desc* d, const void* Q, const voi
   hipStream_t st = (hipStream_t)stream;
   if (d->precision == BEVR_PREC_BF16)
     return launch<BEVR_PREC_BF16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable,
-                                  st);
+                                  st BEVR_DROP_ARGS);
   if (d->precision == BEVR_PREC_F16)
-    return launch<BEVR_PREC_F16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
+    return launch<BEVR_PREC_F16>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st BEVR_DROP_ARGS);
   if (d->precision == BEVR_PREC_BF16X3)
-    return launch<BEVR_PREC_BF16X3>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
-  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st);
+    return launch<BEVR_PREC_BF16X3>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st BEVR_DROP_ARGS);
+  return launch<BEVR_PREC_F32>(*d, Q, K, Kt, V, key_ws, table_pair, dO, LSE, delta, grad_scale, dQ, dtable, st BEVR_DROP_ARGS);
 }

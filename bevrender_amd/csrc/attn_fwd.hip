@@ -70,7 +70,7 @@ template <int PREC>
 __global__ __launch_bounds__(TF, is16(PREC) ? 4 : 2) void attn_fwd_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Vt,
     const char* __restrict__ key_ws, const char* __restrict__ table_pair,
-    float* __restrict__ O, float* __restrict__ LSE) {
+    float* __restrict__ O, float* __restrict__ LSE BEVR_DROP_PARAMS) {
   typedef Lds<PREC> L;
   constexpr int EB = L::EB;
   constexpr int ENT = L::ENT;
@@ -380,6 +380,16 @@ __global__ __launch_bounds__(TF, is16(PREC) ? 4 : 2) void attn_fwd_kernel(
         ls2 += pp;
       }
       l += ls2[0] + ls2[1];
+#if BEVR_DROP
+      {
+        // dropout acts on the normalised weights: the denominator above is of the unmasked ones; a kept weight is scaled
+        const uint32_t hrow = bevr_drop_row(drop_seed, (uint32_t)ph, (uint32_t)(jc * d.Sp + i0 + lq));
+        const float ksc = 65536.0f / (65536.0f - (float)drop_thr);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          s[r] = bevr_drop_keep(hrow, (uint32_t)(step * KT + ks * 32 + crow(r, hi)), drop_thr) ? s[r] * ksc : 0.f;
+      }
+#endif
       PROF_TD(t5, l + s[3]);
       PROF_ADD(3, t5 - t4);
       o = mma_acc_b(vf, s, o);
@@ -431,20 +441,27 @@ __global__ __launch_bounds__(TF, is16(PREC) ? 4 : 2) void attn_fwd_kernel(
 
 template <int PREC>
 int launch_fwd(const bevr_attn_desc& d, const void* Q, const void* K, const void* Vt, const void* key_ws,
-               const float* table_pair, float* O, float* LSE, hipStream_t st) {
+               const float* table_pair, float* O, float* LSE, hipStream_t st BEVR_DROP_PARAMS) {
   const int n_rb = d.Sp / 32, n_cb = (d.S + NWF - 1) / NWF;
   const int n_ph = d.n_prob * d.heads;
   const int grid = ((n_ph + 7) / 8) * 8 * n_rb * n_cb;
   hipLaunchKernelGGL((attn_fwd_kernel<PREC>), dim3(grid), dim3(TF), 0, st, d, (const char*)Q, (const char*)K,
-                     (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O, LSE);
+                     (const char*)Vt, (const char*)key_ws, (const char*)table_pair, O, LSE BEVR_DROP_ARGS);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
+#if BEVR_DROP
+extern "C" int bevr_attn_fwd_dropout(const bevr_attn_desc* d, const void* Q, const void* K, const void* Vt,
+                                     const void* key_ws, const float* table_pair, float* O,
+                                     float* LSE, unsigned drop_thr, unsigned drop_seed, void* stream) {
+  if (drop_thr >= 65536u) return BEVR_E_SHAPE;
+#else
 extern "C" int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* Vt,
                              const void* key_ws, const float* table_pair, float* O,
                              float* LSE, void* stream) {
+#endif
   int rc = bevr_check_desc(d);
   if (rc) return rc;
   if (!Q || !K || !Vt || !key_ws || !table_pair || !O || !LSE) return BEVR_E_NULL;
@@ -452,9 +469,9 @@ extern "C" int bevr_attn_fwd(const bevr_attn_desc* d, const void* Q, const void*
       !bevr_aligned16(table_pair))
     return BEVR_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (d->precision == BEVR_PREC_BF16) return launch_fwd<BEVR_PREC_BF16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
-  if (d->precision == BEVR_PREC_F16) return launch_fwd<BEVR_PREC_F16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
+  if (d->precision == BEVR_PREC_BF16) return launch_fwd<BEVR_PREC_BF16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st BEVR_DROP_ARGS);
+  if (d->precision == BEVR_PREC_F16) return launch_fwd<BEVR_PREC_F16>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st BEVR_DROP_ARGS);
   if (d->precision == BEVR_PREC_BF16X3)
-    return launch_fwd<BEVR_PREC_BF16X3>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
-  return launch_fwd<BEVR_PREC_F32>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st);
+    return launch_fwd<BEVR_PREC_BF16X3>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st BEVR_DROP_ARGS);
+  return launch_fwd<BEVR_PREC_F32>(*d, Q, K, Vt, key_ws, table_pair, O, LSE, st BEVR_DROP_ARGS);
 }

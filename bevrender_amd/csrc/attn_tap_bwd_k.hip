@@ -22,11 +22,7 @@
 
 namespace {
 
-#if BEVR_VARIANT == 8
-constexpr int NKW = 9;                 // key waves per workgroup
-#else
-constexpr int NKW = 7;                 // key waves per workgroup
-#endif
+constexpr int NKW = 7;                 // key waves per workgroup (A/B on the benchmark shape: 3, 5 and 9 are 27-45 % slower)
 constexpr int NCW = 8;                 // table columns of the shared window (a chunk is 4 wide: origins may differ by 4 columns ...
 constexpr int NRX = 8;                 // ... and by 8 rows inside one workgroup)
 struct LdsK {
@@ -49,7 +45,7 @@ __device__ __forceinline__ bool tile_fits(const StepBox& sb, float jrx, int a0w,
 // workgroup without any leaves at once: every workgroup of a cell-sorted segment).  Two launches: with both bodies in one
 // loop the matrix path reloaded loop invariants from scratch on every slab.
 template <int PREC, bool SLOW>
-__global__ __launch_bounds__(64 * (NKW + 1), (NKW == 9 ? 5 : 4)) void attn_tap_bwd_k_kernel(
+__global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
     bevr_attn_desc d, const char* __restrict__ G, const char* __restrict__ H, const char* __restrict__ tap_ws,
     const float* __restrict__ table_t, float* __restrict__ dkey_a, float* __restrict__ dkey_b,
     float* __restrict__ dkey_y, float* __restrict__ dkey_x, int n_wg_ph) {

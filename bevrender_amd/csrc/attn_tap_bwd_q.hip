@@ -16,11 +16,7 @@
 namespace {
 
 template <int PREC, int NB>
-#if BEVR_VARIANT == 7
-__global__ __launch_bounds__(512, (NB == 4 ? 4 : 6)) void attn_tap_bwd_q_kernel(
-#else
 __global__ __launch_bounds__(512, 4) void attn_tap_bwd_q_kernel(
-#endif
     bevr_attn_desc d, const char* __restrict__ G, const char* __restrict__ H, const char* __restrict__ tap_ws, const char* __restrict__ table_pair,
     float* __restrict__ dG, float* __restrict__ dtable) {
   typedef LdsT L;

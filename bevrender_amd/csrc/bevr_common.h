@@ -255,6 +255,35 @@ __device__ __forceinline__ KeyC make_keyc(float a, float b, const bevr_attn_desc
   return k;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Attention dropout (reference model/SCA_deform_attn.py:155,402-409, model/TSA_deform_attn.py:90,313-323: nn.Dropout on
+// the softmax weights, the kept ones scaled by 1 / (1 - p)).  The keep decision of the pair (problem-head ph, packed
+// query mq, key n) is a pure function of (seed, ph, mq, n): the forward and both backward kernels evaluate the same
+// function instead of storing an (M x N) mask.  keep iff the hash's top 16 bits >= thr16, thr16 = round(p * 65536).
+// bevrender_amd/ops.py:dropout_keep_mask is the same function on the host (the tests build the oracle's mask with it).
+__host__ __device__ __forceinline__ uint32_t bevr_drop_mix(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t bevr_drop_row(uint32_t seed, uint32_t ph, uint32_t mq) {
+  return seed ^ (ph * 0x9E3779B1u) ^ (mq * 0x85EBCA77u);
+}
+__host__ __device__ __forceinline__ bool bevr_drop_keep(uint32_t row, uint32_t n, uint32_t thr16) {
+  return (bevr_drop_mix(row ^ (n * 0xC2B2AE3Du)) >> 16) >= thr16;
+}
+// The dropout variants of the region kernels are separate translation units (attn_*_drop.hip: #define BEVR_DROP 1 and
+// #include the kernel's source): the kernels without dropout stay byte for byte what they were.
+#ifndef BEVR_DROP
+#define BEVR_DROP 0
+#endif
+#if BEVR_DROP
+#define BEVR_DROP_PARAMS , unsigned drop_thr, unsigned drop_seed
+#define BEVR_DROP_ARGS , drop_thr, drop_seed
+#else
+#define BEVR_DROP_PARAMS
+#define BEVR_DROP_ARGS
+#endif
+
 static inline int bevr_check_desc(const bevr_attn_desc* d) {
   if (!d) return BEVR_E_NULL;
   if (d->n_prob <= 0 || d->q_div <= 0 || d->n_prob % d->q_div) return BEVR_E_SHAPE;

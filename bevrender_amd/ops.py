@@ -341,6 +341,29 @@ def cell_order(a: torch.Tensor, b: torch.Tensor, n_tail: int = 0) -> torch.Tenso
     return order.gather(1, flag.argsort(dim=1, stable=True))       # tail first, the rest after it, both in cell order
 
 
+def _u32(x):
+    return x & 0xFFFFFFFF
+
+
+def dropout_keep_mask(seed: int, thr16: int, n_ph: int, S: int, N: int, device="cpu") -> torch.Tensor:
+    """The attention-dropout keep mask the kernels evaluate (csrc/bevr_common.h:bevr_drop_keep), on the host:
+    (n_ph, S*S, N) bool, query index m = i*S + j (the reference's flattening), key index n in the kernels' key order.
+    keep iff the hash's top 16 bits >= thr16 = round(p * 65536).  Tests build the oracle's mask with it."""
+    Sp = 32 * ((S + 31) // 32)
+    i = torch.arange(S, dtype=torch.int64, device=device)
+    mq = (i[None, :] * Sp + i[:, None]).reshape(-1)                    # m = i*S + j -> packed j*Sp + i
+    ph = torch.arange(n_ph, dtype=torch.int64, device=device)
+    n = torch.arange(N, dtype=torch.int64, device=device)
+    row = _u32(seed ^ _u32(ph * 0x9E3779B1)[:, None] ^ _u32(mq * 0x85EBCA77)[None, :])       # (n_ph, M)
+    x = _u32(row[:, :, None] ^ _u32(n * 0xC2B2AE3D)[None, None, :])
+    x = x ^ (x >> 16)
+    x = _u32(x * 0x7FEB352D)
+    x = x ^ (x >> 15)
+    x = _u32(x * 0x846CA68B)
+    x = x ^ (x >> 16)
+    return (x >> 16) >= thr16
+
+
 @dataclass
 class _Seg:
     """One key segment of an attention call: keys [n0, n0 + geom.N) of the caller's arrays."""
@@ -358,7 +381,8 @@ class _AttnCore(torch.autograd.Function):
     backward passes of both use the final LSE and delta and accumulate into the same dQ and d(table)."""
 
     @staticmethod
-    def forward(ctx, Qp, kv, key_a, key_b, Tt, geom: AttnGeom, split: int, feat=None, spos=None, Wkv=None, bkv=None):
+    def forward(ctx, Qp, kv, key_a, key_b, Tt, geom: AttnGeom, split: int, feat=None, spos=None, Wkv=None, bkv=None,
+                drop=None):
         """kv (B', N, 2C) projected rows -- or None with the K | V SOURCE instead: feat (B', Hi, Wi, C) channels-last
         feature map (float or bf16), spos (B', N, 2) sampling positions, Wkv (2C, C), bkv (2C,) the proj_k | proj_v
         weights: the operands are then produced by bevr_kv_project (csrc/kvproj.hip: sample -> project -> packed layouts
@@ -366,6 +390,8 @@ class _AttnCore(torch.autograd.Function):
         _require_gpu(Qp, kv, key_a, key_b, Tt, feat, spos, Wkv, bkv)
         L = _lib.lib()
         ed = _edtype(geom.precision)
+        # drop = (thr16, seed): attention dropout, region kernels only (the keep mask is a function of (seed, ph, mq, n))
+        ctx.drop = drop if drop and drop[0] > 0 else None
         x3 = geom.precision == _lib.PREC_BF16X3
         Qe = _split_rows(Qp.float()) if x3 else Qp.to(ed).contiguous()
         fused = kv is None
@@ -384,6 +410,8 @@ class _AttnCore(torch.autograd.Function):
         if split > 0:
             segs.append(_Seg(False, 0, dc_replace(geom, N=split)))
         if split < N:
+            if ctx.drop:
+                raise _lib.BevrError("attention dropout runs on the region kernels: pass no cell segment")
             segs.append(_Seg(True, split, dc_replace(geom, N=N - split)))
         Ttc = Tt.contiguous()
         pair = torch.stack((Ttc[..., :-1], Ttc[..., 1:]), dim=-1).contiguous()   # (h, Wp, Hp, 2)
@@ -426,6 +454,9 @@ class _AttnCore(torch.autograd.Function):
                 _lib.check(KERNEL_TIMER.run("bevr_attn_cell_fwd", _attn_flops(g, 2), L.bevr_attn_cell_fwd, C.byref(d),
                                             _ptr(Qe), _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), o_in, l_in, _ptr(O),
                                             _ptr(LSE), _stream(), tag=_call_tag(g)), "bevr_attn_cell_fwd")
+            elif ctx.drop:
+                _lib.check(L.bevr_attn_fwd_dropout(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O),
+                                                   _ptr(LSE), ctx.drop[0], ctx.drop[1], _stream()), "bevr_attn_fwd_dropout")
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_fwd", _attn_flops(g, 2), L.bevr_attn_fwd, C.byref(d), _ptr(Qe),
                                             _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O), _ptr(LSE),
@@ -522,6 +553,10 @@ class _AttnCore(torch.autograd.Function):
                                             _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
                                             _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream(),
                                             tag=_call_tag(g)), "bevr_attn_cell_bwd_q")
+            elif ctx.drop:
+                _lib.check(L.bevr_attn_bwd_q_dropout(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair),
+                                                     _ptr(dOe), _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT),
+                                                     ctx.drop[0], ctx.drop[1], _stream()), "bevr_attn_bwd_q_dropout")
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(g, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
                                             _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
@@ -537,6 +572,11 @@ class _AttnCore(torch.autograd.Function):
                                             _ptr(Qe), _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
                                             _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dK), _ptr(dV),
                                             _ptr(da), _ptr(db), _stream(), tag=_call_tag(g)), "bevr_attn_cell_bwd_k")
+            elif ctx.drop:
+                _lib.check(L.bevr_attn_bwd_k_dropout(C.byref(d), _ptr(Qe), _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(ka), _ptr(kb),
+                                                     _ptr(pair), _ptr(dOe), _ptr(dOt), _ptr(LSE), _ptr(delta), _ptr(gscale),
+                                                     _ptr(dK), _ptr(dV), _ptr(da), _ptr(db), ctx.drop[0], ctx.drop[1],
+                                                     _stream()), "bevr_attn_bwd_k_dropout")
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_k", _attn_flops(g, 4), L.bevr_attn_bwd_k, C.byref(d), _ptr(Qe),
                                             _ptr(Qt), _ptr(Ke), _ptr(Ve), _ptr(ka), _ptr(kb), _ptr(pair), _ptr(dOe),
@@ -556,7 +596,7 @@ class _AttnCore(torch.autograd.Function):
             inv = 1.0 / sdo
             dQ, dkv, da, db, dT = dQ * inv, dkv * inv, da * inv, db * inv, dT * inv
         if not ctx.fused:
-            return dQ, dkv, da, db, dT, None, None, None, None, None, None
+            return dQ, dkv, da, db, dT, None, None, None, None, None, None, None
         # adjoint of the fused K | V source in its unfused form: the projection's GEMMs on the float samples (recomputed:
         # the forward never wrote them) and the sampler's scatter
         feat, spos, Wkv = src[0], src[1], src[2]
@@ -567,13 +607,13 @@ class _AttnCore(torch.autograd.Function):
         dxs = (d2 @ Wkv.float()).reshape(xs.shape)
         del xs
         dfeat, dspos = _Sample.scatter(feat, spos, dxs, ctx.needs_input_grad[7])
-        return dQ, None, da, db, dT, None, None, dfeat, dspos, dW, dbias
+        return dQ, None, da, db, dT, None, None, dfeat, dspos, dW, dbias, None
 
 
 def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Optional[torch.Tensor], pos: torch.Tensor,
                    rpe_table: torch.Tensor, *, heads: int, groups: int, views: int, precision: int,
                    kv: Optional[torch.Tensor] = None, cell_split: Optional[int] = None, kv_source=None,
-                   tap_source=None) -> torch.Tensor:
+                   tap_source=None, attn_drop=None) -> torch.Tensor:
     """Fused attention of the BEV query against sampled keys.
 
     query (B, C, S, S) layer-normed BEV query (used raw as Q); kproj, vproj (B*views, N, C) projected
@@ -590,10 +630,21 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     pixels of `feat` (the caller's contract: the projector-pinned keys, tap_supported) and go through the TAP kernels
     (csrc/attn_tap.h): their K and V are never formed -- the logits come from G = Q Kpix^T (12 pixels), the output from
     O = Rn Vpix, both thin GEMMs here -- and the segment is merged with the region kernels' through (O, LSE).
+    attn_drop = (p, seed): dropout on the softmax weights (the reference's attn_drop, :402-409): a weight is kept with
+    probability 1 - p (p rounded to 1/65536) and scaled by 1 / (1 - p); the mask is the function dropout_keep_mask of
+    (seed, problem-head, query, key) that the forward and backward kernels share.  Every key then runs on the region
+    kernels (cell_split / tap_source are ignored).
     Returns (B*views, S*S, C): per view softmax(QK^T c^-0.5 + bias) V, rows in i*S + j order.
     Replaces model/SCA_deform_attn.py:304-413 / model/TSA_deform_attn.py:220-333.
     """
     B, Cc, S, _ = query.shape
+    drop = None
+    if attn_drop is not None and attn_drop[0] > 0.0:
+        thr = int(round(float(attn_drop[0]) * 65536.0))
+        if not 0 < thr < 65536:
+            raise ValueError("attention dropout probability must lie in (0, 1)")
+        drop = (thr, int(attn_drop[1]) & 0xFFFFFFFF)
+        cell_split, tap_source = None, None
     if kv_source is not None:
         if kv is not None or kproj is not None or vproj is not None:
             raise ValueError("pass kv_source alone")
@@ -632,9 +683,9 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     Tt = pack_table(rpe_table.float(), geom)
     if not tap:
         if kv_source is not None:
-            O, _ = _AttnCore.apply(Qp, None, a, b, Tt, geom, split, feat, pos.float(), Wkv, bkv)
+            O, _ = _AttnCore.apply(Qp, None, a, b, Tt, geom, split, feat, pos.float(), Wkv, bkv, drop)
         else:
-            O, _ = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split, None, None, None, None)
+            O, _ = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split, None, None, None, None, drop)
         return unpack_out(O, S, c)
 
     # ---- keys [0, split): region kernels; keys [split, N): tap kernels; one softmax, merged through (O, LSE) ----

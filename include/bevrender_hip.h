@@ -43,7 +43,8 @@ extern "C" {
 /* 3: bevr_attn_fwd writes TWO LSE planes (round 2 changed that under version 2: a version-2 caller's [n_prob][heads][Mp]
  *    buffer is too small), the key workspace carries group boxes, bevr_attn_bwd_q takes grad_scale; new: bevr_attn_cell_*,
  *    problem strides of bevr_pack_kv / bevr_unpack_dkv, BEVR_PREC_F16, grad_scale[8] for every backward entry point. */
-/* 4: new entry points bevr_attn_tap_* (the projector-pinned keys without K / V); nothing else changed. */
+/* 4: new entry points bevr_attn_tap_* (the projector-pinned keys without K / V) and bevr_attn_*_dropout; nothing else
+ *    changed. */
 #define BEVR_ABI_VERSION 4
 
 enum {
@@ -172,6 +173,29 @@ int bevr_attn_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt, cons
                     const float* key_a, const float* key_b, const float* table_pair,
                     const void* dO, const void* dOt, const float* LSE, const float* delta, const float* grad_scale,
                     float* dK, float* dV, float* dkey_a, float* dkey_b, void* stream);
+
+/* Attention dropout (nn.Dropout on the softmax weights: model/SCA_deform_attn.py:155,402-409,
+ * model/TSA_deform_attn.py:90,313-323): the three entry points above with a keep mask.  The mask is not stored: pair
+ * (problem-head ph = prob * heads + head, packed query mq, key n) is kept iff
+ *     (mix(seed ^ ph * 0x9E3779B1 ^ mq * 0x85EBCA77 ^ n * 0xC2B2AE3D) >> 16) >= drop_thr,
+ *     mix(x): x ^= x >> 16; x *= 0x7FEB352D; x ^= x >> 15; x *= 0x846CA68B; x ^= x >> 16      (32-bit arithmetic)
+ * with drop_thr = round(p * 65536) < 65536, and a kept weight is scaled by 65536 / (65536 - drop_thr).  The forward
+ * masks the weights AFTER the normalisation (LSE is of the unmasked logits, as the reference's softmax-then-dropout);
+ * the backward entry points evaluate the same function (same seed): dS = P (D dP - delta), dV from D P.  delta is
+ * still rowsum(dO * O).  bevrender_amd/ops.py:dropout_keep_mask is the host twin.  Region kernels only: a caller with
+ * dropout keeps every key on these entry points (the cell / tap entry points have no mask). */
+int bevr_attn_fwd_dropout(const bevr_attn_desc* d, const void* Q, const void* K, const void* Vt,
+                          const void* key_ws, const float* table_pair, float* O, float* LSE,
+                          unsigned drop_thr, unsigned drop_seed, void* stream);
+int bevr_attn_bwd_q_dropout(const bevr_attn_desc* d, const void* Q, const void* K, const void* Kt, const void* V,
+                            const void* key_ws, const float* table_pair, const void* dO, const float* LSE,
+                            const float* delta, const float* grad_scale, float* dQ, float* dtable,
+                            unsigned drop_thr, unsigned drop_seed, void* stream);
+int bevr_attn_bwd_k_dropout(const bevr_attn_desc* d, const void* Q, const void* Qt, const void* K, const void* V,
+                            const float* key_a, const float* key_b, const float* table_pair, const void* dO,
+                            const void* dOt, const float* LSE, const float* delta, const float* grad_scale,
+                            float* dK, float* dV, float* dkey_a, float* dkey_b, unsigned drop_thr, unsigned drop_seed,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Cell-sorted key segments: the same attention with the relative-position bias (and its table gradient) as a small

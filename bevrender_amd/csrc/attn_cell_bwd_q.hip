@@ -495,7 +495,7 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Kt
   if (n_fast > 16) return BEVR_E_SHAPE;
   const size_t lds = 2 * L::BUF + (size_t)n_fast * L::QSLOT;
   const size_t lds_slow = 2 * L::BUF + (size_t)n_rb * L::QSLOT + (size_t)(d.Np / 32) * 4;
-  if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
+  if (lds > 160 * 1024 || lds_slow > 160 * 1024) return BEVR_E_SHAPE;
   if (!is16(PREC) && 64 * n_fast <= 512)
     hipLaunchKernelGGL((attn_cell_bwd_q_kernel<PREC, false, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_fast), lds, st,
                        d, (const char*)Q, (const char*)K, (const char*)Kt, (const char*)V, (const char*)key_ws,

@@ -92,8 +92,8 @@ __device__ __forceinline__ void chunk_map(int g, const char* Kh, const char* Vh,
 template <int PREC, bool SLOW, int MAXT>
 __global__ __launch_bounds__(MAXT) void attn_cell_fwd_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ Vt,
-    const char* __restrict__ key_ws, const char* __restrict__ table_pair, const float* __restrict__ O_in,
-    const float* __restrict__ LSE_in, float* __restrict__ O, float* __restrict__ LSE) {
+    const char* __restrict__ key_ws, const char* __restrict__ table_pair, const float* O_in,
+    const float* LSE_in, float* O, float* LSE) {   // (O_in, LSE_in) may alias (O, LSE): the chained call passes them so
   typedef LdsC<PREC> L;
   constexpr int EB = L::EB;
   // 2 staging buffers | one Q fragment slot per wave | (slow pass) the list of this column's slow tiles
@@ -651,6 +651,9 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Vt
   const int n_fast = n_rb + 1;                // ... + the producer wave (fast pass)
   if (n_fast > 16) return BEVR_E_SHAPE;
   const size_t lds = 2 * L::BUF + (size_t)n_fast * L::QSLOT;
+  // both passes' LDS before anything is launched: the fast pass updates (O, LSE) in place
+  const size_t lds_slow = 2 * L::BUF + (size_t)n_rb * L::QSLOT + (size_t)(d.Np / 32) * 4;
+  if (lds > 160 * 1024 || lds_slow > 160 * 1024) return BEVR_E_SHAPE;
   if (!is16(PREC) && 64 * n_fast <= 512)
     hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, false, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_fast), lds, st,
                        d, (const char*)Q, (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair,
@@ -661,8 +664,6 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* Vt
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   // slow pass, in place: continues from the fast pass's state; no producer; its LDS also holds the list of slow tiles
-  const size_t lds_slow = 2 * L::BUF + (size_t)n_rb * L::QSLOT + (size_t)(d.Np / 32) * 4;
-  if (lds_slow > 160 * 1024) return BEVR_E_SHAPE;
   if (!is16(PREC) && 64 * n_rb <= 512)
     hipLaunchKernelGGL((attn_cell_fwd_kernel<PREC, true, (is16(PREC) ? 1024 : 512)>), dim3(grid), dim3(64 * n_rb), lds_slow, st,
                        d, (const char*)Q, (const char*)K, (const char*)Vt, (const char*)key_ws, (const char*)table_pair,

@@ -218,7 +218,9 @@ constexpr int PCH_KEYS = 256, PCH_BYTES = 48 * 1024, PCH_WMAX = 32;
 // x / gmax * 2^40 as (hi: signed 32 bits, lo: unsigned 32 bits), t = x * 2^8 / gmax in [-256, 256]
 __device__ __forceinline__ unsigned long long to_fixed40(float t) {
   const float h = floorf(t);
-  const unsigned lo = (unsigned)((t - h) * 4294967296.0f);   // t - h exact in f32, in [0, 1)
+  // t - h lies in [0, 1) but ROUNDS to 1.0f for a tiny negative t: clamp below 1 (a float -> unsigned conversion of
+  // 2^32 is out of range: undefined, harmless only because v_cvt_u32_f32 saturates)
+  const unsigned lo = (unsigned)(fminf(t - h, 0x1.fffffep-1f) * 4294967296.0f);
   return ((unsigned long long)(unsigned)(int)h << 32) | lo;
 }
 
@@ -425,7 +427,8 @@ int sample_bwd(const T* feat, const float* pos, const float* dout, float* dfeat,
     hipError_t e = hipMemsetAsync(dpos, 0, (size_t)nb * N * 2 * sizeof(float), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
-  const bool patch_ok = (SB_THREADS % c4n) == 0 && C * 4 * 32 <= PCH_BYTES;
+  // the LDS cells are 8-byte fixed point: the widest window row (PCH_WMAX pixels) must fit
+  const bool patch_ok = (SB_THREADS % c4n) == 0 && C * 8 * PCH_WMAX <= PCH_BYTES;
   if (patch_ok) {
     // chunks of consecutive keys; a workgroup takes several (the hot corner's partials are reduced once per workgroup)
     const int n_chunk = (N + PCH_KEYS - 1) / PCH_KEYS;

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops, resolve_precision
-from .model_utils import LayerNormProxy, trunc_normal_
+from .model_utils import LayerNormProxy, attention_dropout, trunc_normal_
 
 # keys per view and call that move from the cell segment's sparse tail to the region kernels (ops.cell_order)
 CELL_TAIL = int(os.environ.get("BEVR_CELL_TAIL", "128"))
@@ -43,8 +43,8 @@ class SCADeformableAttention(nn.Module):
         self.data_type, self.logger = data_type, logger
         self.offset_range_factor = 5.0
         self.precision = resolve_precision(precision)
-        if attn_drop_rate or proj_drop_rate:
-            raise NotImplementedError("dropout inside the fused attention is not supported (reference default 0)")
+        # reference :155-156: nn.Dropout on the softmax weights and on the projected output (training mode only)
+        self.attn_drop_rate, self.proj_drop_rate = float(attn_drop_rate), float(proj_drop_rate)
         cg, D = self.n_channel_per_group, bev_depth_dim
 
         def head(out_ch):
@@ -147,6 +147,9 @@ class SCADeformableAttention(nn.Module):
         pos = self.key_positions(query, reference_points.to(query.dtype), key_order)   # (B, V, g, N, 2), key order
         N = pos.shape[3]
         pos = pos.reshape(B * V * g, N, 2)
+        drop = attention_dropout(self)      # (p, seed) in training mode with attn_drop_rate > 0, else None
+        if drop is not None:
+            cell_split = None               # the keep mask lives in the region kernels: every key goes there
         if cell_split is not None and cell_split < N and g == 1:
             # groups > 1: a key is one row of K built from all groups' samples, so the groups cannot be ordered
             # independently; the split is simply not used then
@@ -169,12 +172,13 @@ class SCADeformableAttention(nn.Module):
             feat = (xf if xf.dtype == torch.bfloat16 else xf.float()).permute(0, 2, 3, 1).contiguous()
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
                                    precision=self.precision, kv_source=(feat, Wkv, bkv), cell_split=cell_split,
-                                   tap_source=cell_split is not None and self._pinned_keys_tap(S, Hi, Wi))
+                                   tap_source=cell_split is not None and self._pinned_keys_tap(S, Hi, Wi), attn_drop=drop)
         else:
             xs = ops.sample_features(xf, pos, g)                                     # (B*V, N, C)
             kv = F.linear(xs, Wkv, bkv)
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
-                                   precision=self.precision, kv=kv, cell_split=cell_split)   # (B*V, S*S, C)
+                                   precision=self.precision, kv=kv, cell_split=cell_split, attn_drop=drop)   # (B*V, S*S, C)
         o = o.reshape(B, V, S * S, C).permute(0, 2, 1, 3).reshape(B, S * S, V * C)
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
+        out = F.dropout(out, self.proj_drop_rate, self.training)                      # reference :420 (proj_drop)
         return out.permute(0, 2, 1).reshape(B, C, S, S), wandb_log_dict

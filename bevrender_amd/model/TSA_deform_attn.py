@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .. import ops, resolve_precision
-from .model_utils import (LayerNormProxy, _dw_ok, depthwise_conv2d, depthwise_conv2d_nhwc, normalized_grid,
+from .model_utils import (LayerNormProxy, attention_dropout, _dw_ok, depthwise_conv2d, depthwise_conv2d_nhwc, normalized_grid,
                           trunc_normal_)
 
 
@@ -33,8 +33,8 @@ class TSADeformableAttention(nn.Module):
         self.data_type, self.logger = data_type, logger
         self.offset_range_factor = 0.5
         self.precision = resolve_precision(precision)
-        if attn_drop_rate or proj_drop_rate:
-            raise NotImplementedError("dropout inside the fused attention is not supported (reference default 0)")
+        # reference :90-91: nn.Dropout on the softmax weights and on the projected output (training mode only)
+        self.attn_drop_rate, self.proj_drop_rate = float(attn_drop_rate), float(proj_drop_rate)
         pad = kernel_size // 2 if kernel_size != stride else 0
         cg = self.n_channel_per_group
         self.conv_offset = nn.Sequential(
@@ -109,16 +109,18 @@ class TSADeformableAttention(nn.Module):
         # read once instead of twice)
         Wkv = torch.cat((self.proj_k.weight.flatten(1), self.proj_v.weight.flatten(1)), 0)
         bkv = torch.cat((self.proj_k.bias, self.proj_v.bias), 0)
+        drop = attention_dropout(self)      # (p, seed) in training mode with attn_drop_rate > 0, else None
         if x.is_cuda and ops.kv_source_supported(C, self.n_heads, self.n_groups, self.precision):
             # sampling, projection and operand packing as one kernel (csrc/kvproj.hip)
             feat = (x if x.dtype == torch.bfloat16 else x.float()).permute(0, 2, 3, 1).contiguous()
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
-                                   views=1, precision=self.precision, kv_source=(feat, Wkv, bkv))
+                                   views=1, precision=self.precision, kv_source=(feat, Wkv, bkv), attn_drop=drop)
         else:
             xs = ops.sample_features(x, pos, self.n_groups)                              # (B, N, C)
             kv = F.linear(xs, Wkv, bkv)
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
-                                   views=1, precision=self.precision, kv=kv)             # (B, H*W, C)
+                                   views=1, precision=self.precision, kv=kv, attn_drop=drop)   # (B, H*W, C)
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
+        out = F.dropout(out, self.proj_drop_rate, self.training)                      # reference :336 (proj_drop)
         out = out.permute(0, 2, 1).reshape(B, C, H, W)
         return out, wandb_log_dict

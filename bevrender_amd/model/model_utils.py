@@ -94,3 +94,14 @@ def normalized_grid(H: int, W: int, dtype, device) -> torch.Tensor:
 
 def trunc_normal_(t: torch.Tensor, std: float = 1.0):
     return nn.init.trunc_normal_(t, std=std)
+
+
+def attention_dropout(module):
+    """(p, seed) for ops.attention_core(attn_drop=...) when `module` (an SCA / TSA attention module) is training with
+    attn_drop_rate > 0, else None.  The seed comes from torch's CPU generator: reproducible under torch.manual_seed, no
+    device synchronisation; the kernels turn (seed, problem, head, query, key) into the keep decision
+    (ops.dropout_keep_mask), the same in the forward and the backward."""
+    p = getattr(module, "attn_drop_rate", 0.0)
+    if not (module.training and p > 0.0):
+        return None
+    return p, int(torch.randint(0, 2 ** 31 - 1, (1,)).item())

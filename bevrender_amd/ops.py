@@ -674,9 +674,11 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
         raise ValueError("tap_source needs kv_source, groups == 1, the bf16 operand mode and S <= 448")
     geom = AttnGeom(n_prob=Bp, q_div=views, heads=heads, groups=groups, S=S, N=split if tap else N, Wt=Wt, precision=precision)
     f32_layout = precision in (_lib.PREC_F32, _lib.PREC_BF16X3)
-    if not tap and split < N and (geom.Sp > 480 or (f32_layout and geom.Sp > 256)):
+    if not tap and split < N and (geom.Sp > 480 or (f32_layout and geom.Sp > 224) or (N - split) > 8 * 100 * 1024):
         # the cell kernels run one wave per 32-row block of a BEV column + a producer wave, 16 at most; with f32-sized
-        # operands the query-side backward's LDS (2 staging buffers + a Q / dO slot per wave) ends at 8 row blocks
+        # operands the 512-thread instantiation (the one without spills) ends at 7 row blocks + the producer; and the slow
+        # pass lists a segment's tiles in LDS (4 bytes per 32 keys next to the staging buffers): a segment beyond
+        # ~800 000 keys would not fit.  Such calls keep every key on the region kernels (any split is a valid result)
         split = N
     Qp = pack_query(query.float(), heads)
     a, b = key_coords(pos.float(), S, Wt, N)

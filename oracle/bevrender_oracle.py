@@ -64,7 +64,8 @@ def _offset_net(qg: Tensor, p: Dict[str, Tensor], prefix: str, stride: int, pad:
 
 
 def attention_core(q: Tensor, k: Tensor, v: Tensor, pos: Tensor, rpe_table: Tensor,
-                   Hq: int, Wq: int, n_groups: int, scale: float, rows: Optional[Tensor] = None) -> Tensor:
+                   Hq: int, Wq: int, n_groups: int, scale: float, rows: Optional[Tensor] = None,
+                   keep: Optional[Tensor] = None) -> Tensor:
     """Dense softmax attention with bilinear relative-position bias (materialised, as the reference does).
 
     q (B*h, c, M) raw query; k, v (B*h, c, N); pos (B*g, N, 2) key positions (y, x) in [-1,1] units;
@@ -92,6 +93,10 @@ def attention_core(q: Tensor, k: Tensor, v: Tensor, pos: Tensor, rpe_table: Tens
     bias = F.grid_sample(table, disp[..., (1, 0)], mode="bilinear", align_corners=True)  # (B*g, h/g, M, N)
     attn = attn + bias.reshape(Bh, M, N)
     attn = F.softmax(attn, dim=2)
+    if keep is not None:
+        # attn_drop (model/SCA_deform_attn.py:402-409: nn.Dropout after the softmax) with an explicit mask: `keep`
+        # (B*h, M, N) holds 0 or 1 / (1 - p), what nn.Dropout multiplies by in training mode
+        attn = attn * keep
     return torch.einsum("bmn,bcn->bcm", attn, v)
 
 
@@ -427,7 +432,11 @@ def triplet_margin_loss(cam: Tensor, mp: Tensor, miner_margin: float = 0.2, loss
       loss   TripletMarginLoss(margin=0.05, distance=CosineSimilarity()): relu(cos_an - cos_ap + margin) per mined
              triplet (an inverted distance: larger = closer);
       reduce ThresholdReducer(high=0.3): mean over the triplet losses < high (zeros included), 0 if none passes;
-      plus   LpRegularizer() (p=2) on the raw embeddings with the default weight 1 and MeanReducer: mean ||e||_2.
+      plus   LpRegularizer() (p=2) on the raw embeddings with the default weight 1: mean ||e||_2 here.  UNVERIFIED which
+             reducer the library applies to that term when the loss is built with `reducer=`: it may copy the caller's
+             reducer onto every sub-loss, in which case ThresholdReducer(high=0.3) would also gate the norms (and drop
+             every embedding whose norm exceeds 0.3); this restatement assumes a plain mean.  The package is absent here
+             and the reference holds no test or fixture for this loss, so nothing decides it.
     Written as the triple loop the library's index lists amount to."""
     B = cam.shape[0]
     emb = torch.cat((cam, mp), 0)

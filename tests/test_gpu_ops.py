@@ -200,10 +200,13 @@ def test_projector_matches_reference_golden(name):
     pts = pillar_grid({"X": X, "Y": Y, "Z": Z}, int(S), int(D), float(zs))
     got = torch.stack(proj.bev_grid_to_camera(pts)[0], 0).cpu().numpy()
     want = z["points_2d"]
-    _check_projection(got, want, pts, list(z["imu_to_rgb"]), list(z["K"]), int(iw), int(ih), int(ow), int(oh), name)
+    # the committed fixtures: the integer-truncation mask is reproduced bit for bit (no point flips its in-bound decision);
+    # the boundary tolerance of _check_projection is for the random rigs of the sweep only
+    _check_projection(got, want, pts, list(z["imu_to_rgb"]), list(z["K"]), int(iw), int(ih), int(ow), int(oh), name,
+                      max_flip_frac=0.0)
 
 
-def _check_projection(got, want, pts, T, K, iw, ih, ow, oh, tag):
+def _check_projection(got, want, pts, T, K, iw, ih, ow, oh, tag, max_flip_frac=1e-3):
     """Every point agrees to 1e-5, except points whose in-bound decision FLIPPED: the mask is an integer truncation of
     a float pixel, so a pixel within float rounding of one of the four bounds may legitimately land on either side.
     The flips are counted, printed, and each one must be such a boundary case (pixel recomputed in float64)."""
@@ -226,7 +229,7 @@ def _check_projection(got, want, pts, T, K, iw, ih, ow, oh, tag):
             for i in np.nonzero(flip[cam])[0]:
                 d = min(abs(u[i]), abs(u[i] - (iw - 1)), abs(v[i]), abs(v[i] - (ih - 1)))
                 assert d < 1e-3, f"{tag}: cam {cam} point {i} flipped at pixel ({u[i]:.5f}, {v[i]:.5f}), not a boundary case"
-    assert n_flip <= 1e-3 * flip.size
+    assert n_flip <= max_flip_frac * flip.size, f"{tag}: {n_flip} in-bound decisions flipped"
 
 
 def test_projector_grey_pixel_mask(tmp_path):

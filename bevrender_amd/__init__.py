@@ -11,9 +11,11 @@ __all__ = ["default_precision", "_lib"]
 
 
 def default_precision() -> int:
-    """BEVRENDER_PRECISION=f32|bf16x3|bf16|f16 (default f32: exact-f32 MFMA; bf16x3: f32 storage, products as three
-    split-bf16 MFMAs, f32 tolerance; bf16: the throughput mode; f16: fp16 operands)."""
-    v = os.environ.get("BEVRENDER_PRECISION", "f32").lower()
+    """BEVRENDER_PRECISION=bf16x3|f32|bf16|f16.  Default bf16x3 (round 4): f32 storage and per-pair
+    arithmetic, matrix products as three split-bf16 MFMAs -- the reference's fp32 results to ~1e-5 (the tests hold it
+    to the exact mode's limits) at twice the exact mode's speed.  f32: exact-f32 MFMA; bf16: the throughput mode (the
+    benchmark's); f16: fp16 operands."""
+    v = os.environ.get("BEVRENDER_PRECISION", "bf16x3").lower()
     if v in ("bf16", "bfloat16"):
         return _lib.PREC_BF16
     if v in ("f16", "fp16", "float16", "half"):

@@ -106,21 +106,30 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
     // the key waves may still be one step behind, in the last slab of column j - 1 ---------------------------------------
     __builtin_amdgcn_s_setprio(3);
     const int n_quad = (NRWD + 1) / 2, n_item = NCW * n_quad;
-    auto fill = [&](int jn, int it) {       // item = (column c, rows 4 m .. 4 m + 4) of the window of BEV column jn
-      if (it >= n_item) return;
+    // item = (column c, rows 4 m .. 4 m + 4) of the window of BEV column jn: five table values in, hi / lo parts of the row
+    // pairs (4 m, + 1), (+ 2, + 3) [parity 0] and (+ 1, + 2), (+ 3, + 4) [parity 1] out.  Load and store are separate
+    // steps: the loads of one slice are in flight across a barrier (they sat on the workgroup's critical path when the
+    // producer waited for them before every barrier)
+    auto item_load = [&](int jn, int it, float (&t)[5]) {
+      if (it >= n_item || jn >= d.S) return;
       const int c = it / n_quad, m = it - c * n_quad;
       const int x0w = (int)floorf((float)jn * rx + bminw);
       const int xc = max(0, min(x0w + c + d.x_off, d.Wp - 1));
       // rows past the padded table are never weighted: clamp the run's start (the table's last rows are zero padding)
       const int y = max(0, min(a0w + d.y_off + 4 * m, HpT - 5));
       const float* src = tbl + (size_t)xc * HpT + y;
-      const float t0 = src[0], t1 = src[1], t2 = src[2], t3 = src[3], t4 = src[4];
-      const uint32_t h01 = Half<PREC>::pack2(t0, t1), h23 = Half<PREC>::pack2(t2, t3);
-      const uint32_t h12 = Half<PREC>::pack2(t1, t2), h34 = Half<PREC>::pack2(t3, t4);
-      const uint32_t l01 = Half<PREC>::pack2(t0 - Half<PREC>::lo(h01), t1 - Half<PREC>::hi(h01));
-      const uint32_t l23 = Half<PREC>::pack2(t2 - Half<PREC>::lo(h23), t3 - Half<PREC>::hi(h23));
-      const uint32_t l12 = Half<PREC>::pack2(t1 - Half<PREC>::lo(h12), t2 - Half<PREC>::hi(h12));
-      const uint32_t l34 = Half<PREC>::pack2(t3 - Half<PREC>::lo(h34), t4 - Half<PREC>::hi(h34));
+#pragma unroll
+      for (int k = 0; k < 5; ++k) t[k] = src[k];
+    };
+    auto item_store = [&](int jn, int it, const float (&t)[5]) {
+      if (it >= n_item || jn >= d.S) return;
+      const int c = it / n_quad, m = it - c * n_quad;
+      const uint32_t h01 = Half<PREC>::pack2(t[0], t[1]), h23 = Half<PREC>::pack2(t[2], t[3]);
+      const uint32_t h12 = Half<PREC>::pack2(t[1], t[2]), h34 = Half<PREC>::pack2(t[3], t[4]);
+      const uint32_t l01 = Half<PREC>::pack2(t[0] - Half<PREC>::lo(h01), t[1] - Half<PREC>::hi(h01));
+      const uint32_t l23 = Half<PREC>::pack2(t[2] - Half<PREC>::lo(h23), t[3] - Half<PREC>::hi(h23));
+      const uint32_t l12 = Half<PREC>::pack2(t[1] - Half<PREC>::lo(h12), t[2] - Half<PREC>::hi(h12));
+      const uint32_t l34 = Half<PREC>::pack2(t[3] - Half<PREC>::lo(h34), t[4] - Half<PREC>::hi(h34));
       uint32_t* w = reinterpret_cast<uint32_t*>(win_base + (jn % 3) * win_bytes) + c * NRWD + 2 * m;
       const bool second = 2 * m + 1 < NRWD;
       w[0] = h01;
@@ -134,8 +143,22 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
         w[3 * NCW * NRWD + 1] = l34;
       }
     };
-    if constexpr (!SLOW)
-      for (int it = lane; it < n_item; it += 64) fill(0, it);
+    // the slice of the next column's window that step (j, s) writes: items [s per_step, (s + 1) per_step), two per lane
+    const int per_step = (n_item + nslab - 1) / nslab;
+    auto slice_item = [&](int s2, int r) {
+      const int k = r * 64 + lane;
+      return k < per_step ? s2 * per_step + k : n_item;
+    };
+    float f0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, f1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (!SLOW) {
+      for (int it = lane; it < n_item; it += 64) {   // column 0's window, whole, before the first step
+        float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        item_load(0, it, t);
+        item_store(0, it, t);
+      }
+      item_load(1, slice_item(0, 0), f0);
+      item_load(1, slice_item(0, 1), f1);
+    }
     const char* Gp = G + ((size_t)ph * Mp) * 32 + lane * 16;
     const char* Hq = H + ((size_t)ph * Mp) * 32 + lane * 16;
     int e = 0;
@@ -145,12 +168,17 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
         char* bb = smem + (e & 1) * L::BUF;
         *reinterpret_cast<u32x4*>(bb + L::OFF_G + lane * 16) = gv;
         *reinterpret_cast<u32x4*>(bb + L::OFF_H + lane * 16) = hv;
-        const int e2 = min(e + 1, d.S * nslab - 1);     // the next slab's rows are in flight across the barrier
+        if constexpr (!SLOW) {
+          item_store(j + 1, slice_item(s, 0), f0);
+          item_store(j + 1, slice_item(s, 1), f1);
+        }
+        const int e2 = min(e + 1, d.S * nslab - 1);     // the next slab's rows and the next window slice: in flight across the barrier
         gv = gload16(Gp + (size_t)e2 * 1024);
         hv = gload16(Hq + (size_t)e2 * 1024);
         if constexpr (!SLOW) {
-          if (j + 1 < d.S)
-            for (int it = lane + 64 * s; it < n_item; it += 64 * nslab) fill(j + 1, it);
+          const int jn = s + 1 < nslab ? j + 1 : j + 2, sn = s + 1 < nslab ? s + 1 : 0;
+          item_load(jn, slice_item(sn, 0), f0);
+          item_load(jn, slice_item(sn, 1), f1);
         }
         __syncthreads();
       }
@@ -375,7 +403,8 @@ int launch(const bevr_attn_desc& d, const void* G, const void* H, const void* ta
   const int n_tiles = d.Np / 32;
   const int n_wg_ph = (n_tiles + NKW - 1) / NKW;
   const size_t lds = 2 * L::BUF + (size_t)3 * 4 * NCW * win_dwords(d.Sp) * 4 + NKW * 32 * sizeof(TapRec);
-  if (lds > 160 * 1024) return BEVR_E_SHAPE;
+  // the producer carries two window items per lane and step: NCW * ceil(win_dwords / 2) items over Sp / 32 steps
+  if (lds > 160 * 1024 || (NCW * ((win_dwords(d.Sp) + 1) / 2) + d.Sp / 32 - 1) / (d.Sp / 32) > 128) return BEVR_E_SHAPE;
   const long long grid = (long long)((n_ph + 7) / 8) * 8 * n_wg_ph;
   if (grid > 0x7fffffffLL) return BEVR_E_SHAPE;
   hipLaunchKernelGGL((attn_tap_bwd_k_kernel<PREC, false>), dim3((unsigned)grid), dim3(64 * (NKW + 1)), lds, st, d, (const char*)G,

@@ -9,7 +9,7 @@
 // projection-weight gradients follow from dG (bwd_q) and the forward's R by thin GEMMs in the caller.
 //
 // Key-stationary: a wave owns one 32-key tile (two 16-key matrix tiles), a workgroup 7 tiles + a PRODUCER wave that
-// stages the query side -- the rows G[q][.], H[q][.] of one 32-row slab of one BEV column per step -- through LDS; one
+// stages the query side -- the rows G[q][.], H[q][.] of two 32-row slabs of one BEV column per step -- through LDS; one
 // barrier per step.  S[q][n] comes out with the key on the lane, so P and dS are the B operands of the Z products as they
 // stand; the transposed query-side operands (G^T, H^T) come out of the staged rows through ds_read_b64_tr_b16.
 // The table: per column a wave copies the 4 columns x (S + 4) rows its chunk can touch into a PRIVATE LDS window, as
@@ -25,10 +25,16 @@ namespace {
 constexpr int NKW = 7;                 // key waves per workgroup (A/B on the benchmark shape: 3, 5 and 9 are 27-45 % slower)
 constexpr int NCW = 8;                 // table columns of the shared window (a chunk is 4 wide: origins may differ by 4 columns ...
 constexpr int NRX = 8;                 // ... and by 8 rows inside one workgroup)
+#if BEVR_VARIANT == 10
+constexpr int SPB = 1;
+#else
+constexpr int SPB = 2;                 // 32-row slabs per step (= per barrier)
+#endif
 struct LdsK {
   static constexpr int OFF_G = 0;      // [32 rows][16 slots] 16-bit
   static constexpr int OFF_H = 1024;
-  static constexpr int BUF = 2048;
+  static constexpr int SLAB = 2048;    // one slab's G | H rows
+  static constexpr int BUF = SPB * SLAB;
 };
 // dwords per (kind, parity, column) of a window: rows 0 .. Sp + NRX + 7, two rows per dword
 __host__ __device__ __forceinline__ int win_dwords(int Sp) { return (Sp + NRX + 8) / 2; }
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int Mp = d.S * d.Sp;
-  const int nslab = d.Sp / 32;
+  const int nslab = d.Sp / 32, nstep = (nslab + SPB - 1) / SPB;
   const int n_tiles = d.Np / 32;
   const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
   const int HpT = d.Hp + 1;                                   // rows of a column of the plain transposed table
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
       }
     };
     // the slice of the next column's window that step (j, s) writes: items [s per_step, (s + 1) per_step), two per lane
-    const int per_step = (n_item + nslab - 1) / nslab;
+    const int per_step = (n_item + nstep - 1) / nstep;
     auto slice_item = [&](int s2, int r) {
       const int k = r * 64 + lane;
       return k < per_step ? s2 * per_step + k : n_item;
@@ -161,24 +167,44 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
     }
     const char* Gp = G + ((size_t)ph * Mp) * 32 + lane * 16;
     const char* Hq = H + ((size_t)ph * Mp) * 32 + lane * 16;
+    // slab `sl` (0 .. S nslab - 1, column-major) of the packed rows starts sl * 1024 bytes in; a step stages SPB slabs
+    auto slab_index = [&](int j2, int st2, int u) { return min(j2 * nslab + min(SPB * st2 + u, nslab - 1), d.S * nslab - 1); };
     int e = 0;
-    u32x4 gv = gload16(Gp), hv = gload16(Hq);
+    u32x4 gv[SPB], hv[SPB];
+#pragma unroll
+    for (int u = 0; u < SPB; ++u) {
+      gv[u] = gload16(Gp + (size_t)slab_index(0, 0, u) * 1024);
+      hv[u] = gload16(Hq + (size_t)slab_index(0, 0, u) * 1024);
+    }
     for (int j = 0; j < d.S; ++j) {
-      for (int s = 0; s < nslab; ++s, ++e) {
+      for (int st = 0; st < nstep; ++st, ++e) {
         char* bb = smem + (e & 1) * L::BUF;
-        *reinterpret_cast<u32x4*>(bb + L::OFF_G + lane * 16) = gv;
-        *reinterpret_cast<u32x4*>(bb + L::OFF_H + lane * 16) = hv;
-        if constexpr (!SLOW) {
-          item_store(j + 1, slice_item(s, 0), f0);
-          item_store(j + 1, slice_item(s, 1), f1);
+#pragma unroll
+        for (int u = 0; u < SPB; ++u) {
+          *reinterpret_cast<u32x4*>(bb + u * L::SLAB + L::OFF_G + lane * 16) = gv[u];
+          *reinterpret_cast<u32x4*>(bb + u * L::SLAB + L::OFF_H + lane * 16) = hv[u];
         }
-        const int e2 = min(e + 1, d.S * nslab - 1);     // the next slab's rows and the next window slice: in flight across the barrier
-        gv = gload16(Gp + (size_t)e2 * 1024);
-        hv = gload16(Hq + (size_t)e2 * 1024);
         if constexpr (!SLOW) {
-          const int jn = s + 1 < nslab ? j + 1 : j + 2, sn = s + 1 < nslab ? s + 1 : 0;
-          item_load(jn, slice_item(sn, 0), f0);
-          item_load(jn, slice_item(sn, 1), f1);
+          item_store(j + 1, slice_item(st, 0), f0);
+          item_store(j + 1, slice_item(st, 1), f1);
+          // a slice beyond the two pipelined items per lane (short columns: few steps share the window): on the spot
+          for (int k = 128 + lane; k < per_step; k += 64) {
+            float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            item_load(j + 1, st * per_step + k, t);
+            item_store(j + 1, st * per_step + k, t);
+          }
+        }
+        // the next step's rows and the next window slice: in flight across the barrier
+        const int jn = st + 1 < nstep ? j : min(j + 1, d.S - 1), stn = st + 1 < nstep ? st + 1 : 0;
+#pragma unroll
+        for (int u = 0; u < SPB; ++u) {
+          gv[u] = gload16(Gp + (size_t)slab_index(jn, stn, u) * 1024);
+          hv[u] = gload16(Hq + (size_t)slab_index(jn, stn, u) * 1024);
+        }
+        if constexpr (!SLOW) {
+          const int jf = st + 1 < nstep ? j + 1 : j + 2;
+          item_load(jf, slice_item(stn, 0), f0);
+          item_load(jf, slice_item(stn, 1), f1);
         }
         __syncthreads();
       }
@@ -217,7 +243,11 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
 
   int e = 0;
   float jrx = 0.f;
-  const uint32_t* win = nullptr;   // this column's window, at this tile's chunk origin
+  // this column's window and this lane's byte offsets into it at slab 0 (a row is 2 bytes, so slab i0 is 2 i0 further; the
+  // row parity of a lane's reads does not change from slab to slab): the plain cell reads of the S operand (columns
+  // 2 (g - 2) and + 1) and the transposed reads of the Z operands (hi and lo parts)
+  const char* win_b = nullptr;
+  int wq0 = 0, wq1 = 0, wth = 0, wtl = 0;
   // one 32-row slab of column j against this wave's 32 keys.  FIT: the tile's taps fit one chunk inside the window (bias
   // and its position gradient through the matrix cores); else the per-pair gather from the table in global memory
   auto slab = [&](auto fit_tag, const char* base, int i0) {
@@ -231,11 +261,12 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
         v = *reinterpret_cast<const u32x4*>(base + a_row + rb * 512);
         hv = *reinterpret_cast<const u32x4*>(base + L::OFF_H - L::OFF_G + a_row + rb * 512);
       } else if (FIT) {
-        // the chunk's cells for BEV row i: columns 2 (g - 2), + 1; rows i .. i + 3 of the window
-        const int i = i0 + 16 * rb + li + da, par = i & 1;
-        const uint32_t* w0 = win + (par * NCW + 2 * (g - 2)) * NRWD + ((i - par) >> 1);
+        // the chunk's cells for BEV row i0 + 16 rb + li: columns 2 (g - 2), + 1; rows i .. i + 3 of the window (addresses
+        // prepared per column: wq0 / wq1; a slab is 16 dwords further, the second row block 8 more)
+        const uint32_t* w0 = reinterpret_cast<const uint32_t*>(win_b + wq0 + 2 * i0) + 8 * rb;
+        const uint32_t* w1 = reinterpret_cast<const uint32_t*>(win_b + wq1 + 2 * i0) + 8 * rb;
         v[0] = w0[0]; v[1] = w0[1];
-        v[2] = w0[NRWD]; v[3] = w0[NRWD + 1];
+        v[2] = w1[0]; v[3] = w1[1];
       }
       qa[rb] = __builtin_bit_cast(bf16x8, v);
       ha[rb] = __builtin_bit_cast(bf16x8, hv);
@@ -244,11 +275,10 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
     const bf16x8 ht = lds_tr8(base + L::OFF_H + t_off, 512);
     bf16x8 thi = gt, tlo = gt;
     if constexpr (FIT) {
-      const int v1 = i0 + 4 * g + cell_r + da, par = v1 & 1;
-      const uint32_t* w0 = win + (par * NCW + cell_c) * NRWD + ((v1 - par) >> 1);
+      const uint32_t* w0 = reinterpret_cast<const uint32_t*>(win_b + wth + 2 * i0);
+      const uint32_t* w1 = reinterpret_cast<const uint32_t*>(win_b + wtl + 2 * i0);
       u32x4 a, b;
       a[0] = w0[0]; a[1] = w0[1]; a[2] = w0[8]; a[3] = w0[9];
-      const uint32_t* w1 = w0 + 2 * NCW * NRWD;
       b[0] = w1[0]; b[1] = w1[1]; b[2] = w1[8]; b[3] = w1[9];
       thi = __builtin_bit_cast(bf16x8, a);
       tlo = __builtin_bit_cast(bf16x8, b);
@@ -336,11 +366,22 @@ __global__ __launch_bounds__(64 * (NKW + 1), 4) void attn_tap_bwd_k_kernel(
       }
       zc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    win = reinterpret_cast<const uint32_t*>(win_base + (j % 3) * win_bytes) + dx * NRWD;
-    for (int s = 0; s < nslab; ++s, ++e) {
+    win_b = win_base + (j % 3) * win_bytes;
+    {
+      const int iq = li + da, pq = iq & 1;                       // plain reads: window row of BEV row li (row block 0)
+      wq0 = ((pq * NCW + dx + 2 * max(g - 2, 0)) * NRWD + ((iq - pq) >> 1)) * 4;
+      wq1 = wq0 + NRWD * 4;
+      const int it = 4 * g + cell_r + da, pt = it & 1;           // transposed reads: rows 4 g + cell_r .. + 3 and + 16 ..
+      wth = ((pt * NCW + dx + cell_c) * NRWD + ((it - pt) >> 1)) * 4;
+      wtl = wth + 2 * NCW * NRWD * 4;
+    }
+    for (int st = 0; st < nstep; ++st, ++e) {
       __syncthreads();
       if (!mine) continue;
-      slab(std::integral_constant<bool, !SLOW>{}, smem + (e & 1) * L::BUF, 32 * s);
+#pragma unroll
+      for (int u = 0; u < SPB; ++u)
+        if (SPB * st + u < nslab)
+          slab(std::integral_constant<bool, !SLOW>{}, smem + (e & 1) * L::BUF + u * L::SLAB, 32 * (SPB * st + u));
     }
     // ---- the column's bias-position gradients out of Z: this lane holds chunk column c = g, rows 0..3 of its key ----
     if (!SLOW && mine) {
@@ -403,8 +444,7 @@ int launch(const bevr_attn_desc& d, const void* G, const void* H, const void* ta
   const int n_tiles = d.Np / 32;
   const int n_wg_ph = (n_tiles + NKW - 1) / NKW;
   const size_t lds = 2 * L::BUF + (size_t)3 * 4 * NCW * win_dwords(d.Sp) * 4 + NKW * 32 * sizeof(TapRec);
-  // the producer carries two window items per lane and step: NCW * ceil(win_dwords / 2) items over Sp / 32 steps
-  if (lds > 160 * 1024 || (NCW * ((win_dwords(d.Sp) + 1) / 2) + d.Sp / 32 - 1) / (d.Sp / 32) > 128) return BEVR_E_SHAPE;
+  if (lds > 160 * 1024) return BEVR_E_SHAPE;
   const long long grid = (long long)((n_ph + 7) / 8) * 8 * n_wg_ph;
   if (grid > 0x7fffffffLL) return BEVR_E_SHAPE;
   hipLaunchKernelGGL((attn_tap_bwd_k_kernel<PREC, false>), dim3((unsigned)grid), dim3(64 * (NKW + 1)), lds, st, d, (const char*)G,

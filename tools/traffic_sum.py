@@ -13,7 +13,8 @@ root, batch, cmd, sha = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
 NAMES = {"attn_fwd_kernel": "bevr_attn_fwd", "attn_bwd_q_kernel": "bevr_attn_bwd_q", "attn_bwd_k_win_kernel": "bevr_attn_bwd_k",
          "attn_bwd_k_gather_kernel": "bevr_attn_bwd_k", "sample_fwd_kernel": "bevr_sample_fwd", "sample_bwd_kernel": "bevr_sample_bwd", "sample_bwd_patch_kernel": "bevr_sample_bwd", "kv_project_kernel": "bevr_kv_project",
          "attn_cell_fwd_kernel": "bevr_attn_cell_fwd", "attn_cell_bwd_q_kernel": "bevr_attn_cell_bwd_q",
-         "attn_cell_bwd_k_kernel": "bevr_attn_cell_bwd_k"}
+         "attn_cell_bwd_k_kernel": "bevr_attn_cell_bwd_k", "attn_tap_fwd_kernel": "bevr_attn_tap_fwd",
+         "attn_tap_bwd_q_kernel": "bevr_attn_tap_bwd_q", "attn_tap_bwd_k_kernel": "bevr_attn_tap_bwd_k"}
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(int))
 for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -28,7 +29,8 @@ for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             acc[k][counter] += float(r["Counter_Value"]) * 1024.0
             # one entry point = one launch: the gather kernel rides with the window kernel, a cell kernel's slow pass
             # (template argument true) with its fast pass
-            if "gather" not in m.group(1) and not re.search(r"attn_cell_\w+_kernel<\d+, true", r["Kernel_Name"]):
+            # (the tap kernels' second launches -- exact pass <.., true>, slow pass <.., true> -- ride with the first)
+            if "gather" not in m.group(1) and not re.search(r"attn_(cell|tap)_\w+_kernel<[\d, ]*true", r["Kernel_Name"]):
                 launches[k][counter] += 1
 out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `" + cmd + "`; bytes summed over the "
                    "launches of the timed AND warm-up step, averaged per launch (bwd_k = window + gather kernels of one call). "

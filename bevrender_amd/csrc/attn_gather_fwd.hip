@@ -1,0 +1,536 @@
+// Forward of the GATHER kernels: attention over SCATTERED keys (the camera-visible keys of SCA in their static k-d
+// order, TSA's keys) with every product on the matrix cores, 16-bit operand modes.
+//     S[n][q] = scale Q_q . K_n + bias[n][q],   bias = bilinear sample of the rpe table at (i + a_n, j rx + b_n)
+//     O_q     = softmax_n(S) V                  (model/SCA_deform_attn.py:331-413, model/TSA_deform_attn.py:245-333)
+// Same operands, key workspace and outputs (O normalised, two LSE planes) as bevr_attn_fwd (attn_fwd.hip), which it
+// replaces for the 16-bit modes; the table arrives as 16-bit PAIRS, table_pk[h][Wp][Hp] = (T2[y][x], T2[y + 1][x]).
+//
+// The bias as a matrix product with a SPARSE contraction: a 16-key tile has 64 slots, slot (key n', tap) -- the four
+// bilinear taps of key n' in the order (y, x), (y + 1, x), (y, x + 1), (y + 1, x + 1):
+//     bias^T[n][q] = sum_slots W[n][slot] Tg[slot][q],    W[n][(n', tap)] = w_tap(n) [n' == n],
+//                                                          Tg[(n', tap)][q] = T2[A_n' + i_q + dy][X_n' + dx]
+// Tg is the B operand exactly as the lanes GATHER it: lane (q, k-group) holds the slots of two keys = two dwords (one per
+// table column, each a (y, y + 1) pair) per key -- one ds_read2_b32 per key from an LDS WINDOW of the pair table; the 16
+// lanes of a k-group read 16 consecutive rows of one column.  W is block diagonal: an LDS image that is zero except for
+// the 8 bytes (four packed weights) each key owns.  Per 16 keys x 16 BEV rows: 3 MFMAs for S (QK^T + 2 x bias), 1 for
+// PV, 4 LDS gathers; no per-pair arithmetic but the exponential.
+//
+// Work split (as the tap kernels, attn_tap_fwd.hip): workgroup = ONE BEV column j of one (problem, head); wave w owns
+// the 16-row blocks [w NB, (w + 1) NB) of the column; the LAST wave is the PRODUCER.  Per emission (one 32-key tile) it
+// stages the K rows, the V rows (two 16-channel images for the transposed reads of the PV product), the W image, every
+// key's window address, and the WINDOW itself: the columns [x0, x1] x rows [a0, a0 + PITCH) of the pair table that the
+// tile's taps reach for ALL BEV rows of the column (a k-d leaf of 32 keys: ~13 columns x ~225 rows, 12 KB, one 16-byte
+// load per lane and column).  Two buffers: the producer fills emission e + 1 while the row-block waves work on e; one
+// barrier per emission.
+//
+// ANY key set is handled: a tile whose box does not fit the window (more than WIN_COLS columns or PITCH rows) is emitted
+// in groups of 14 keys with one two-column STRIP of the table per key, the other keys masked.
+//
+// Softmax reference: the maximum of the row's first tile, raised (with a rescale) only when a later logit exceeds it
+// by more than 2^RAISE -- weights up to 2^RAISE are exact in bf16 and in the f32 sums.  The exact row maximum is
+// tracked beside it for LSE plane 1.
+#include "attn_tap.h"
+
+#ifdef BEVR_GPROF
+__device__ unsigned long long bevr_prof_gather[32];
+extern "C" int bevr_debug_prof_gather(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[32] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(bevr_prof_gather), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bevr_prof_gather), 32 * 8);
+}
+__device__ __forceinline__ unsigned long long gprof_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#define GPROF(var) const unsigned long long var = gprof_now()
+#define GPROF_ADD(i, v) gacc[i] += (v)
+#else
+#define GPROF(var)
+#define GPROF_ADD(i, v)
+#endif
+
+namespace {
+
+constexpr int GT = 32;                 // keys per emission
+constexpr int PITCH = 252;             // window rows (dwords) per column: ds_read2_b32 reaches the next column as offset1
+constexpr int WIN_COLS = 28;
+constexpr int STRIP_KEYS = WIN_COLS / 2;
+struct LdsG {
+  static constexpr int K_PITCH = 80;                    // K rows: 64 B + 16 (conflict-free 16-byte fragment reads)
+  static constexpr int OFF_K = 0;                       // [32 keys][80 B]
+  static constexpr int OFF_VLO = GT * K_PITCH;          // [32 keys][16 channels] 16-bit: channels 0..15
+  static constexpr int OFF_VHI = OFF_VLO + GT * 32;     // channels 16..31
+  static constexpr int OFF_W = OFF_VHI + GT * 32;       // [32 keys] 2 dwords: packed weights of column x | x + 1, each (y, y + 1)
+  static constexpr int OFF_OFF = OFF_W + GT * 8;        // [32 keys] LDS byte address of tap (y, x) for BEV row 0
+  static constexpr int OFF_CT = OFF_OFF + GT * 4;       // u32x4: flags (bit 2: done), live-key mask, entries of the fill list, 0
+  static constexpr int OFF_FD = OFF_CT + 16;            // fill list of the NEXT emission's window: [WIN_COLS] (column, first row)
+  static constexpr int BUF = OFF_FD + WIN_COLS * 8;
+  static constexpr int WIN = WIN_COLS * PITCH * 4;
+  static constexpr int OFF_WIN = 2 * BUF;
+  static constexpr int TOTAL = OFF_WIN + 2 * WIN;
+};
+static_assert(LdsG::BUF % 16 == 0 && LdsG::WIN % 16 == 0, "16-byte aligned LDS blocks");
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight
+// (s_waitcnt vmcnt(0)), which put the memory latency of the producer's prefetches -- issued just before the barrier
+// on purpose -- on every emission's critical path.
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr float RAISE = 40.0f;   // binades a logit may exceed the reference before the reference moves
+
+template <int PREC, int NB, bool EXACT>
+__global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
+    bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ V,
+    const char* __restrict__ key_ws, const uint32_t* __restrict__ table_pk, const float* __restrict__ mref,
+    float* __restrict__ O, float* __restrict__ LSE, int* __restrict__ flags) {
+  typedef LdsG L;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int n_ph = d.n_prob * d.heads;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ph = (slot / d.S) * 8 + xcd;
+  if (ph >= n_ph) return;
+  const int j = slot % d.S;
+  if constexpr (EXACT) {
+    if (flags[ph * d.S + j] == 0) return;
+  }
+  const int prob = ph / d.heads, hd = ph % d.heads;
+  const int tid = threadIdx.x, n_wave = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 15, kg = lane >> 4;
+  const int Mp = d.S * d.Sp;
+  const int nblk = (d.S + QB - 1) / QB;
+  const int rows_q = nblk * QB;
+  const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
+  const float jrx = (float)j * rx;
+  typedef char __attribute__((address_space(3)))* lds_cp;
+  const unsigned smem_base = (unsigned)(size_t)(lds_cp)smem;     // window addresses are handed over as LDS addresses
+
+  // ---- the window fill, shared by ALL waves: entry c of a fill list = (padded table column, first table row) of window
+  // column c.  Entries [0, FILL_P) are the producer's, entry FILL_P + w row-block wave w's: loaded when an emission
+  // starts and stored when it ends (the L2 latency hides behind the emission's matrix work; the row-block waves have
+  // no registers to spare for more than one column).  Entries past those (one window in ten) are copied in place.
+  const char* tbl = reinterpret_cast<const char*>(table_pk + (size_t)hd * d.Wp * d.Hp);
+  constexpr int FILL_P = 8;
+  const int fill_ov = FILL_P + n_wave - 1;      // entries with an owner
+  auto load_col_at = [&](int xc, int r0) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (lane < PITCH / 4) {
+      const int rr = r0 + 4 * lane;
+      const char* src = tbl + ((size_t)xc * d.Hp + rr) * 4;
+      if (rr + 4 <= d.Hp) {
+        v = *reinterpret_cast<const u32x4*>(src);
+      } else {       // the end of a table shorter than a window column
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (rr + k < d.Hp) v[k] = *reinterpret_cast<const uint32_t*>(src + 4 * k);
+      }
+    }
+    return v;
+  };
+  auto load_col = [&](const int* fd, int c) { return load_col_at(fd[2 * c], fd[2 * c + 1]); };
+  auto store_col = [&](char* win, int c, const u32x4& v) {
+    if (lane < PITCH / 4) *reinterpret_cast<u32x4*>(win + (c * PITCH) * 4 + lane * 16) = v;
+  };
+  auto fill_rest = [&](const int* fd, char* win, int nfill, int first) {
+    for (int c = first; c < nfill; c += n_wave) store_col(win, c, load_col(fd, c));
+  };
+
+  if (wave == n_wave - 1) {
+    // ---- producer ------------------------------------------------------------------------------------------
+#if BEVR_VARIANT != 1
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const int pg = prob * d.groups + hd / (d.heads / d.groups);
+    const KeyW* kws = reinterpret_cast<const KeyW*>(key_ws) + (size_t)pg * d.Np;
+    const StepBox* box = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / 32);
+    const char* Kp = K + (size_t)ph * d.Np * 64;
+    const char* Vp = V + (size_t)ph * d.Np * 64;
+    const int n_tiles = d.Np / GT;
+    const int kl = lane & 31, half = lane >> 5;
+
+    // One emission: the keys `sel` of a tile, their rows, weights and window offsets, and the fill list of its window
+    // (this lane's entry).  The producer runs ONE emission ahead: emission e + 1 is described before e is staged, so that
+    // the fill list of window e + 1 travels with emission e.
+    struct Em {
+      unsigned sel;
+      int nfill, fd_xc, fd_r0, koff;
+      u32x2 w;
+    };
+    u32x4 kr[2], vr[2];      // K / V rows of the emission described last: loaded then, staged one emission later
+    // the tile the generator is in (records prefetched one tile ahead)
+    int tile = -1;
+    unsigned rem = 0u;
+    KeyW kw_n = kws[kl];
+    StepBox sb_n = box[0];
+    auto fetch_kv = [&](int t) {
+      const size_t n = (size_t)t * GT + kl;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        kr[i] = *reinterpret_cast<const u32x4*>(Kp + n * 64 + 32 * half + 16 * i);
+        vr[i] = *reinterpret_cast<const u32x4*>(Vp + n * 64 + 32 * half + 16 * i);
+      }
+    };
+    int ar = 0, xc = 0, x0 = 0, a0w = 0, cols = 0;
+    bool fits = false;
+    u32x2 w_t = {0u, 0u};
+    auto advance = [&](Em& em) -> bool {
+      while (rem == 0u) {      // on to the next tile with live keys
+        if (++tile >= n_tiles) return false;
+        const KeyW kw = kw_n;
+        const StepBox sb = sb_n;
+        if (tile + 1 < n_tiles) {
+          kw_n = kws[(size_t)(tile + 1) * GT + kl];
+          sb_n = box[tile + 1];
+        }
+        if (sb.amax < sb.amin) continue;               // a tile of padding only
+        const bool live = tile * GT + kl < d.N;
+        ar = (kw.aoff >> 3) - d.x_off * d.Hp;          // padded table row of tap (y, .) for BEV row 0
+        const float tx = jrx + kw.b;
+        const float xf = floorf(tx);
+        xc = (int)xf + d.x_off;                        // padded table column of tap (., x)
+        const float fx = tx - xf, fy = kw.fy;
+        w_t[0] = Half<PREC>::pack2((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy);
+        w_t[1] = Half<PREC>::pack2(fx * (1.0f - fy), fx * fy);
+        // the tile's box: columns [x0, x1], rows [a0, a0 + rspan)
+        x0 = (int)floorf(jrx + sb.bmin) + d.x_off;
+        const int x1 = (int)floorf(jrx + sb.bmax) + 1 + d.x_off;
+        cols = x1 - x0 + 1;
+        fits = cols <= WIN_COLS && sb.amax - sb.amin + rows_q + 1 <= PITCH;
+        a0w = max(0, min(sb.amin + d.y_off, d.Hp - PITCH));
+        rem = (unsigned)__ballot(live && half == 0);
+      }
+      em.w = w_t;
+      fetch_kv(tile);
+      if (fits) {
+        em.sel = rem;
+        em.koff = ((xc - x0) * PITCH + (ar - a0w)) * 4;
+        em.nfill = cols;
+        em.fd_xc = x0 + lane;
+        em.fd_r0 = a0w;
+      } else {
+        // the first STRIP_KEYS remaining keys, one two-column strip each: entry 2 rank + {0, 1}
+        const int rank = __builtin_popcount(rem & ((1u << kl) - 1u));
+        const bool mine = (rem >> kl & 1u) && rank < STRIP_KEYS;
+        em.sel = (unsigned)__ballot(mine && half == 0);
+        const int akw = max(0, min(ar, d.Hp - PITCH));
+        em.koff = (2 * rank * PITCH + (ar - akw)) * 4;
+        em.nfill = 2 * __builtin_popcount(em.sel);
+        // lane 2 r + c holds the entry of the key with rank r: fetch that key's (xc, akw)
+        const unsigned long long mm = __ballot(mine && half == 0);
+        int src = 0;       // lane of the key with rank (lane >> 1)
+        {
+          unsigned long long t = mm;
+          for (int k = 0; k < (lane >> 1) && t; ++k) t &= t - 1;
+          src = t ? __builtin_ctzll(t) : 0;
+        }
+        em.fd_xc = __shfl(xc, src) + (lane & 1);
+        em.fd_r0 = __shfl(akw, src);
+      }
+      rem &= ~em.sel;
+      return true;
+    };
+    // staging of emission e, in two parts: the keys' operands (before the next emission is described: its K / V rows
+    // take over the registers) and the control record with the fill list of the next window
+    auto stage_keys = [&](const Em& em, int e) {
+      char* bb = smem + (e & 1) * L::BUF;
+      // K, V: lane = (key, 32-byte half of the row)
+      *reinterpret_cast<u32x4*>(bb + L::OFF_K + kl * L::K_PITCH + 32 * half) = kr[0];
+      *reinterpret_cast<u32x4*>(bb + L::OFF_K + kl * L::K_PITCH + 32 * half + 16) = kr[1];
+      char* vimg = bb + (half ? L::OFF_VHI : L::OFF_VLO) + kl * 32;
+      *reinterpret_cast<u32x4*>(vimg) = vr[0];
+      *reinterpret_cast<u32x4*>(vimg + 16) = vr[1];
+      if (half == 0) {
+        *reinterpret_cast<u32x2*>(bb + L::OFF_W + kl * 8) = em.w;
+        // a key outside the emission: any address inside the window (its logit is masked)
+        const bool in = em.sel >> kl & 1u;
+        *reinterpret_cast<unsigned*>(bb + L::OFF_OFF + kl * 4) = smem_base + L::OFF_WIN + (e & 1) * L::WIN + (in ? em.koff : 0);
+      }
+    };
+    auto stage_ct = [&](const Em& em, int e, const Em* nxt) {
+      char* bb = smem + (e & 1) * L::BUF;
+      if (nxt && lane < nxt->nfill) {
+        int* fd = reinterpret_cast<int*>(bb + L::OFF_FD);
+        fd[2 * lane] = nxt->fd_xc;
+        fd[2 * lane + 1] = nxt->fd_r0;
+      }
+      if (lane == 0) *reinterpret_cast<u32x4*>(bb + L::OFF_CT) = u32x4{0u, em.sel, nxt ? (unsigned)nxt->nfill : 0u, 0u};
+    };
+
+    Em cur, nxt;
+    advance(cur);       // N >= 1: there is a first emission
+    {                   // prologue: the fill list of window 0 travels in buffer 1
+      int* fd = reinterpret_cast<int*>(smem + L::BUF + L::OFF_FD);
+      if (lane < cur.nfill) {
+        fd[2 * lane] = cur.fd_xc;
+        fd[2 * lane + 1] = cur.fd_r0;
+      }
+      if (lane == 0) *reinterpret_cast<u32x4*>(smem + L::BUF + L::OFF_CT) = u32x4{0u, 0u, (unsigned)cur.nfill, 0u};
+      barrier_lds();
+      fill_rest(fd, smem + L::OFF_WIN, cur.nfill, wave);
+    }
+#ifdef BEVR_GPROF
+    unsigned long long gacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int e = 0;; ++e) {
+      GPROF(p0);
+      stage_keys(cur, e);      // waits for the K / V rows of this emission only: nothing younger is in flight yet
+      GPROF(p1);
+      // the producer's columns of window e (window 0 is the prologue's); the fill list comes out of the lanes' registers
+      const int nf = e > 0 ? cur.nfill : 0;
+      u32x4 fv[FILL_P];
+#pragma unroll
+      for (int k = 0; k < FILL_P; ++k)
+        if (k < nf) fv[k] = load_col_at(__builtin_amdgcn_readlane(cur.fd_xc, k), __builtin_amdgcn_readlane(cur.fd_r0, k));
+      GPROF(p1b);
+      const bool more = advance(nxt);
+      stage_ct(cur, e, more ? &nxt : nullptr);
+      GPROF(p2);
+      {
+        char* wcur = smem + L::OFF_WIN + (e & 1) * L::WIN;
+#pragma unroll
+        for (int k = 0; k < FILL_P; ++k)
+          if (k < nf) store_col(wcur, k, fv[k]);
+        GPROF(p3a);
+        GPROF_ADD(2, p3a - p2);
+        for (int c = fill_ov + wave; c < nf; c += n_wave)
+          store_col(wcur, c, load_col_at(__builtin_amdgcn_readlane(cur.fd_xc, c), __builtin_amdgcn_readlane(cur.fd_r0, c)));
+      }
+      GPROF(p3);
+      barrier_lds();
+      GPROF(p4);
+      GPROF_ADD(0, p1 - p0);
+      GPROF_ADD(6, p1b - p1);
+      GPROF_ADD(1, p2 - p1b);
+      GPROF_ADD(3, p3 - p2);
+      GPROF_ADD(4, p4 - p3);
+      GPROF_ADD(5, 1);
+      if (!more) {
+        if (lane == 0) *reinterpret_cast<u32x4*>(smem + ((e + 1) & 1) * L::BUF + L::OFF_CT) = u32x4{4u, 0u, 0u, 0u};
+        barrier_lds();
+        break;
+      }
+      cur = nxt;
+    }
+#ifdef BEVR_GPROF
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof_gather[i], gacc[i]);
+#endif
+    return;
+  }
+
+  // ---- row-block waves --------------------------------------------------------------------------------------
+  const int blk0 = wave * NB;
+  const int qb = prob / d.q_div;
+  bf16x8 qf[NB];          // B operand of QK^T: Q[q][8 kg ..]
+  f32x4 o_lo[NB], o_hi[NB];
+  f32x4 negm[NB];         // minus the softmax reference: the accumulator start of every logit product
+  f32x2 lsum[NB];         // row sum, two partial sums (packed adds)
+  float pmx[NB];          // an upper bound of the largest weight (a partial sum of four)
+  unsigned qoff[NB];      // byte offset of the lane's BEV row in a window column
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int row = min(blk0 + nb, nblk - 1) * QB + li;
+    const size_t mcol = (size_t)j * d.Sp + row;
+    qf[nb] = __builtin_bit_cast(
+        bf16x8, *reinterpret_cast<const u32x4*>(Q + ((((size_t)qb * d.heads + hd) * Mp + mcol) * 32 + 8 * kg) * 2));
+    qoff[nb] = (unsigned)row * 4u;
+    o_lo[nb] = o_hi[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float mr = EXACT ? 0.f : mref[(size_t)ph * Mp + mcol];
+    negm[nb] = f32x4{-mr, -mr, -mr, -mr};
+    lsum[nb] = f32x2{0.f, 0.f};
+    pmx[nb] = 0.f;
+  }
+  const int t_off = (4 * kg + (li >> 2)) * 32 + (lane & 3) * 8;      // transposed reads of a [key][16] image
+  typedef const uint32_t __attribute__((address_space(3)))* lds_u32p;
+
+  {   // prologue: window 0
+    barrier_lds();
+    const int nf0 = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u32x4*>(smem + L::BUF + L::OFF_CT)[0][2]);
+    fill_rest(reinterpret_cast<const int*>(smem + L::BUF + L::OFF_FD), smem + L::OFF_WIN, nf0, wave);
+  }
+  bool first = true;      // EXACT only
+#ifdef BEVR_GPROF
+  unsigned long long gacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long cprev = gprof_now();
+#endif
+  for (int e = 0;; ++e) {
+    GPROF(c0);
+    barrier_lds();
+    GPROF(c1);
+    GPROF_ADD(0, c1 - c0);
+    GPROF_ADD(4, c0 - cprev);
+    GPROF_ADD(5, 1);
+#ifdef BEVR_GPROF
+    cprev = c1;
+#endif
+    const char* bb = smem + (e & 1) * L::BUF;
+    const u32x4 ct = *reinterpret_cast<const u32x4*>(bb + L::OFF_CT);
+    if (__builtin_amdgcn_readfirstlane((int)ct[0]) & 4) break;
+    const unsigned livem = (unsigned)__builtin_amdgcn_readfirstlane((int)ct[1]);
+    // this wave's share of the next window: loads now, stores after the emission's work
+    const int nfill = __builtin_amdgcn_readfirstlane((int)ct[2]);
+    const int* fd = reinterpret_cast<const int*>(bb + L::OFF_FD);
+    u32x4 fv = {0u, 0u, 0u, 0u};
+    if (FILL_P + wave < nfill) fv = load_col(fd, FILL_P + wave);
+    const bf16x8 vlo = lds_tr8(bb + L::OFF_VLO + t_off, 512);
+    const bf16x8 vhi = lds_tr8(bb + L::OFF_VHI + t_off, 512);
+    u32x4 pw[NB];          // the tile's weights, packed: the B operand of PV
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if ((livem >> (16 * s2) & 0xffffu) == 0u) {      // uniform: no key of this sub-tile in the emission
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) pw[nb][2 * s2] = pw[nb][2 * s2 + 1] = 0u;
+        continue;
+      }
+      const bf16x8 kf = __builtin_bit_cast(
+          bf16x8, *reinterpret_cast<const u32x4*>(bb + L::OFF_K + (16 * s2 + li) * L::K_PITCH + 16 * kg));
+      // W: lane (key li, k-group kg) holds the slots of keys 8 m + 2 kg + {0, 1} of product m: its own key's weights or 0
+      const u32x2 w4 = *reinterpret_cast<const u32x2*>(bb + L::OFF_W + (16 * s2 + li) * 8);
+      const bool m00 = li == 2 * kg, m01 = li == 2 * kg + 1, m10 = li == 8 + 2 * kg, m11 = li == 9 + 2 * kg;
+      const u32x4 a0 = {m00 ? w4[0] : 0u, m00 ? w4[1] : 0u, m01 ? w4[0] : 0u, m01 ? w4[1] : 0u};
+      const u32x4 a1 = {m10 ? w4[0] : 0u, m10 ? w4[1] : 0u, m11 ? w4[0] : 0u, m11 ? w4[1] : 0u};
+      const bf16x8 wa0 = __builtin_bit_cast(bf16x8, a0), wa1 = __builtin_bit_cast(bf16x8, a1);
+      // window addresses of keys 2 kg, 2 kg + 1 (first bias product) and 8 + 2 kg, 9 + 2 kg (second)
+      const u32x2 oc0 = *reinterpret_cast<const u32x2*>(bb + L::OFF_OFF + (16 * s2 + 2 * kg) * 4);
+      const u32x2 oc1 = *reinterpret_cast<const u32x2*>(bb + L::OFF_OFF + (16 * s2 + 8 + 2 * kg) * 4);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if (NB > 1 && blk0 + nb >= nblk) continue;
+        u32x4 g0, g1;
+        {
+          const lds_u32p p0 = (lds_u32p)(uintptr_t)(oc0[0] + qoff[nb]), p1 = (lds_u32p)(uintptr_t)(oc0[1] + qoff[nb]);
+          const lds_u32p p2 = (lds_u32p)(uintptr_t)(oc1[0] + qoff[nb]), p3 = (lds_u32p)(uintptr_t)(oc1[1] + qoff[nb]);
+          g0[0] = p0[0]; g0[1] = p0[PITCH]; g0[2] = p1[0]; g0[3] = p1[PITCH];
+          g1[0] = p2[0]; g1[1] = p2[PITCH]; g1[2] = p3[0]; g1[3] = p3[PITCH];
+        }
+        f32x4 sv = mfma16<PREC>(kf, qf[nb], negm[nb]);
+        sv = mfma16<PREC>(wa0, __builtin_bit_cast(bf16x8, g0), sv);
+        sv = mfma16<PREC>(wa1, __builtin_bit_cast(bf16x8, g1), sv);
+        if ((livem >> (16 * s2) & 0xffffu) != 0xffffu) {      // uniform: padding keys, or a strip emission
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!(livem >> (16 * s2 + 4 * kg + r) & 1u)) sv[r] = -1.0e30f;
+        }
+        if constexpr (EXACT) {
+          // online reference: the maximum of the row's first keys, raised (with a rescale) when a later logit exceeds it
+          const float tm = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+          if (first || __any(tm > RAISE)) {
+            float tx = fmaxf(tm, __shfl_xor(tm, 16));
+            tx = fmaxf(tx, __shfl_xor(tx, 32));
+            const float delta = first ? tx : fmaxf(tx, 0.f);
+            const float al = first ? 1.0f : fast_exp2(-delta);
+            negm[nb] -= delta;
+            o_lo[nb] *= al;
+            o_hi[nb] *= al;
+            lsum[nb] *= al;
+            pmx[nb] *= al;
+            sv -= delta;
+            if (s2 == 1) {       // the first sub-tile's weights of this tile are in pw already
+              pw[nb][0] = Half<PREC>::pack2(Half<PREC>::lo(pw[nb][0]) * al, Half<PREC>::hi(pw[nb][0]) * al);
+              pw[nb][1] = Half<PREC>::pack2(Half<PREC>::lo(pw[nb][1]) * al, Half<PREC>::hi(pw[nb][1]) * al);
+            }
+          }
+        }
+        const f32x2 pa = {fast_exp2(sv[0]), fast_exp2(sv[1])}, pb2 = {fast_exp2(sv[2]), fast_exp2(sv[3])};
+        pw[nb][2 * s2] = Half<PREC>::pack2(pa[0], pa[1]);
+        pw[nb][2 * s2 + 1] = Half<PREC>::pack2(pb2[0], pb2[1]);
+        const f32x2 ps = pa + pb2;
+        lsum[nb] += ps;
+        pmx[nb] = fmaxf(fmaxf(pmx[nb], ps[0]), ps[1]);
+      }
+      if constexpr (EXACT) first = false;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if (NB > 1 && blk0 + nb >= nblk) continue;
+      const bf16x8 pb = __builtin_bit_cast(bf16x8, pw[nb]);
+      o_lo[nb] = mfma16<PREC>(vlo, pb, o_lo[nb]);
+      o_hi[nb] = mfma16<PREC>(vhi, pb, o_hi[nb]);
+    }
+    {
+      GPROF(c2);
+      GPROF_ADD(1, c2 - c1);
+      char* wnext = smem + L::OFF_WIN + ((e + 1) & 1) * L::WIN;
+      if (FILL_P + wave < nfill) store_col(wnext, FILL_P + wave, fv);
+      GPROF(c3);
+      GPROF_ADD(2, c3 - c2);
+      fill_rest(fd, wnext, nfill, fill_ov + wave);
+      GPROF(c4);
+      GPROF_ADD(3, c4 - c3);
+    }
+  }
+#ifdef BEVR_GPROF
+  if (lane == 0 && (wave == 0 || wave == 3)) for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof_gather[8 + (wave ? 8 : 0) + i], gacc[i]);
+#endif
+
+  // ---- epilogue: O[q][16 half + 4 kg ..], the two LSE planes; flag the column if a row's mass is not a healthy number ----
+  bool bad = false;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    if (blk0 + nb >= nblk) continue;
+    float l = lsum[nb][0] + lsum[nb][1];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    float pm = fmaxf(pmx[nb], __shfl_xor(pmx[nb], 16));
+    pm = fmaxf(pm, __shfl_xor(pm, 32));
+    const int row = (blk0 + nb) * QB + li;
+    if (!EXACT && row < d.S && !(l >= 7.9e-31f && l < 3.0e38f)) bad = true;
+    // rows past the grid (zero Q rows of the last block) get their O and LSE like any other: the key-side backward
+    // walks all Sp rows of a column and needs a finite LSE there; the rows no block covers take the last block's
+    const float inv = 1.0f / l;
+    const size_t mq = (size_t)ph * Mp + (size_t)j * d.Sp + row;
+    float* orow = O + mq * 32;
+    *reinterpret_cast<f32x4*>(orow + 4 * kg) = o_lo[nb] * inv;
+    *reinterpret_cast<f32x4*>(orow + 16 + 4 * kg) = o_hi[nb] * inv;
+    if (kg == 0) {
+      const float lg = __log2f(l);
+      const int n_copy = (blk0 + nb == nblk - 1) ? (d.Sp - row + QB - 1) / QB : 1;
+      for (int k = 0; k < n_copy; ++k) {
+        LSE[mq + k * QB] = lg - negm[nb][0];
+        // plane 1: log2 of an upper bound of the row's largest softmax weight (a partial sum of two weights)
+        LSE[(size_t)n_ph * Mp + mq + k * QB] = __log2f(pm) - lg;
+      }
+    }
+  }
+  if constexpr (!EXACT) {
+    if (__any(bad) && lane == 0) flags[ph * d.S + j] = 1;
+  }
+}
+
+template <int PREC>
+int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* V, const void* key_ws,
+           const void* table_pk, const float* mref, float* O, float* LSE, int* flags, hipStream_t st) {
+  typedef LdsG L;
+  const int n_ph = d.n_prob * d.heads;
+  const int grid = ((n_ph + 7) / 8) * 8 * d.S;
+  const int nblk = (d.S + QB - 1) / QB;
+  // a key's taps for all BEV rows of a column must fit one window column
+  if (nblk * QB + 1 > PITCH || nblk > 14) return BEVR_E_SHAPE;
+  const int nb = nblk <= 7 ? 1 : 2;      // row blocks per wave: at most 7 row-block waves + the producer
+  const int n_cw = (nblk + nb - 1) / nb;
+  const dim3 block(64 * (n_cw + 1));
+#define BEVR_GATHER_LAUNCH(NB_, EX_)                                                                                 \
+  hipLaunchKernelGGL((attn_gather_fwd_kernel<PREC, NB_, EX_>), dim3(grid), block, L::TOTAL, st, d, (const char*)Q,  \
+                     (const char*)K, (const char*)V, (const char*)key_ws, (const uint32_t*)table_pk, mref, O, LSE, flags)
+  for (int ex = 0; ex < 2; ++ex) {       // static reference, then the exact pass over the flagged columns
+    if (nb == 1) { if (ex) BEVR_GATHER_LAUNCH(1, true); else BEVR_GATHER_LAUNCH(1, false); }
+    else { if (ex) BEVR_GATHER_LAUNCH(2, true); else BEVR_GATHER_LAUNCH(2, false); }
+    const int rc = (int)hipGetLastError();
+    if (rc) return rc;
+  }
+#undef BEVR_GATHER_LAUNCH
+  return BEVR_OK;
+}
+
+}  // namespace
+
+extern "C" int bevr_attn_gather_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* V,
+                                    const void* key_ws, const void* table_pk, const float* mref, float* O, float* LSE,
+                                    int* flags, void* stream) {
+  int rc = bevr_check_desc(d);
+  if (rc) return rc;
+  if (!Q || !K || !V || !key_ws || !table_pk || !mref || !O || !LSE || !flags) return BEVR_E_NULL;
+  if (!bevr_aligned16(Q) || !bevr_aligned16(K) || !bevr_aligned16(V) || !bevr_aligned16(O) || !bevr_aligned16(key_ws))
+    return BEVR_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->precision == BEVR_PREC_BF16) return launch<BEVR_PREC_BF16>(*d, Q, K, V, key_ws, table_pk, mref, O, LSE, flags, st);
+  return BEVR_E_PRECISION;
+}

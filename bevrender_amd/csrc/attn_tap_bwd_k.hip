@@ -12,9 +12,10 @@
 // stages the query side -- the rows G[q][.], H[q][.] of two 32-row slabs of one BEV column per step -- through LDS; one
 // barrier per step.  S[q][n] comes out with the key on the lane, so P and dS are the B operands of the Z products as they
 // stand; the transposed query-side operands (G^T, H^T) come out of the staged rows through ds_read_b64_tr_b16.
-// The table: per column a wave copies the 4 columns x (S + 4) rows its chunk can touch into a PRIVATE LDS window, as
-// 16-bit hi and lo parts (Z is differenced in d a / d b: with the hi part alone the position gradient carries the
-// table's 2^-9 rounding) and in two row-parity copies (4 consecutive rows are one aligned
+// The table: per column the producer copies the 8 columns x (S + 16) rows the workgroup's chunks can touch into a SHARED
+// LDS window (three of them in rotation, filled one column ahead in slices), as 16-bit hi and lo parts (Z is differenced
+// in d a / d b: with the hi part alone the position gradient carries the table's 2^-9 rounding) and
+// in two row-parity copies (4 consecutive rows are one aligned
 // ds_read2_b32 for any first row).  A tile whose taps do not fit one chunk for a column takes the per-pair gather for
 // that column (any key set is handled; a cell-sorted segment never does).
 #include <type_traits>
@@ -25,11 +26,7 @@ namespace {
 constexpr int NKW = 7;                 // key waves per workgroup (A/B on the benchmark shape: 3, 5 and 9 are 27-45 % slower)
 constexpr int NCW = 8;                 // table columns of the shared window (a chunk is 4 wide: origins may differ by 4 columns ...
 constexpr int NRX = 8;                 // ... and by 8 rows inside one workgroup)
-#if BEVR_VARIANT == 10
-constexpr int SPB = 1;
-#else
-constexpr int SPB = 2;                 // 32-row slabs per step (= per barrier)
-#endif
+constexpr int SPB = 2;                 // 32-row slabs per step (= per barrier; one per barrier: 27.5 against 24.4 ms)
 struct LdsK {
   static constexpr int OFF_G = 0;      // [32 rows][16 slots] 16-bit
   static constexpr int OFF_H = 1024;

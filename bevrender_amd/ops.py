@@ -372,6 +372,12 @@ class _Seg:
     geom: AttnGeom
 
 
+def gather_supported(precision) -> bool:
+    """Do scattered keys run on the gather kernels (csrc/attn_gather_*.hip: bias on the matrix cores, table taps
+    gathered from L2) instead of the region kernels?  bf16 operands only; BEVR_GATHER=0 turns them off (A/B timing)."""
+    return precision == _lib.PREC_BF16 and os.environ.get("BEVR_GATHER", "0") == "1"
+
+
 class _AttnCore(torch.autograd.Function):
     """O = softmax(Q K^T + bias(a, b, table)) V in packed layouts (all inputs float32).
 
@@ -421,6 +427,7 @@ class _AttnCore(torch.autograd.Function):
         LSE = torch.full((2, geom.n_prob, geom.heads, geom.Mp), float("-inf"), device=dev, dtype=torch.float32)
         need_bwd = any(ctx.needs_input_grad)
         saved = []
+        pair_pk = None
         for i, sg in enumerate(segs):
             g = sg.geom
             # K | V rows (B', N, 2 h c) float -> the kernels' per-head layouts in one pass (csrc/pack.hip); the
@@ -457,6 +464,20 @@ class _AttnCore(torch.autograd.Function):
             elif ctx.drop:
                 _lib.check(L.bevr_attn_fwd_dropout(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O),
                                                    _ptr(LSE), ctx.drop[0], ctx.drop[1], _stream()), "bevr_attn_fwd_dropout")
+            elif gather_supported(g.precision):
+                if pair_pk is None:
+                    pair_pk = pair.to(torch.bfloat16)       # (h, Wp, Hp, 2) 16-bit: one dword per (column, row) entry
+                    tmax = Ttc.abs().amax(dim=(1, 2))       # Tt is the table in log2 units already
+                    qn = torch.linalg.vector_norm(Qe, dim=-1, dtype=torch.float32)          # (B, h, Mp)
+                # static softmax reference: |Q_q . K_n| <= ||Q_q|| max_n ||K_n||, |bias| <= max |T2| (a convex combination;
+                # 1 % for the 16-bit rounding of operands and weights), minus the headroom
+                kmx = torch.linalg.vector_norm(Ke[:, :, :g.N], dim=-1, dtype=torch.float32).amax(-1)    # (B', h)
+                ub = 1.01 * (qn.repeat_interleave(g.q_div, 0) * kmx[..., None] + tmax[None, :, None]) + 0.01
+                mref = (ub - TAP_HEADROOM).contiguous()
+                gflags = torch.zeros(g.n_prob * g.heads * g.S, device=dev, dtype=torch.int32)
+                _lib.check(KERNEL_TIMER.run("bevr_attn_gather_fwd", _attn_flops(g, 2), L.bevr_attn_gather_fwd, C.byref(d),
+                                            _ptr(Qe), _ptr(Ke), _ptr(Ve), _ptr(key_ws), _ptr(pair_pk), _ptr(mref), _ptr(O),
+                                            _ptr(LSE), _ptr(gflags), _stream(), tag=_call_tag(g)), "bevr_attn_gather_fwd")
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_fwd", _attn_flops(g, 2), L.bevr_attn_fwd, C.byref(d), _ptr(Qe),
                                             _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O), _ptr(LSE),

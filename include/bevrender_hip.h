@@ -275,6 +275,23 @@ int bevr_attn_tap_bwd_k(const bevr_attn_desc* d, const void* G, const void* H, c
                         const float* table_pair, float* dkey_a, float* dkey_b, float* dkey_y, float* dkey_x, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Gather kernels: the attention of bevr_attn_fwd / _bwd_* for SCATTERED keys with the relative-position bias on the
+ * matrix cores (csrc/attn_gather_fwd.hip: a sparse contraction whose table side the lanes gather from an LDS window of
+ * the table; any key set is handled).  BEVR_PREC_BF16 only, S <= 224.  Replaces model/SCA_deform_attn.py:331-413 and
+ * model/TSA_deform_attn.py:245-333 (reference) like the entry points above.
+ *   Q, K, key_ws, O, LSE: as bevr_attn_fwd        V [n_prob][heads][Np][32] bf16 rows (not transposed)
+ *   table_pk [heads][Wp][Hp] dwords: the pair table in bf16, (T2[y - y_off][x - x_off], T2[y + 1 - y_off][x - x_off]),
+ *            round-to-nearest of table_pair
+ *   mref [n_prob][heads][Mp] float: the softmax reference of every row, as bevr_attn_tap_fwd's -- an upper bound of the
+ *            row's logits minus a headroom (64 binades); rows whose weights all underflow against it (bound looser than
+ *            ~160 binades) are recomputed with an online maximum: flags [n_prob * heads][S] int, zeroed by the caller,
+ *            marks their columns (scratch)
+ * LSE plane 1 is log2 of an upper bound (within 2 binades) of the row's largest softmax weight. */
+int bevr_attn_gather_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* V,
+                         const void* key_ws, const void* table_pk, const float* mref, float* O, float* LSE,
+                         int* flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Bilinear feature sampling, align_corners=True, zero padding (grid_sample semantics).
  *   feat [nb][Hi][Wi][C] float (channels-last)     pos [nb][N][2] float, (y, x) in [-1, 1] units
  *   out  [nb][N][C] float

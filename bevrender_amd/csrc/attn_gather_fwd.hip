@@ -51,18 +51,19 @@ __device__ __forceinline__ unsigned long long gprof_now() {
 
 namespace {
 
-constexpr int GT = 32;                 // keys per emission
+constexpr int GT = 32;                 // keys per emission (one 32-key tile; 64: two tiles that share one window -- too
+                                       // wide for WIN_COLS at the benchmark: 1.7x the emissions)
+constexpr int NT = GT / 32;
 constexpr int PITCH = 252;             // window rows (dwords) per column: ds_read2_b32 reaches the next column as offset1
 constexpr int WIN_COLS = 28;
 constexpr int STRIP_KEYS = WIN_COLS / 2;
 struct LdsG {
-  static constexpr int K_PITCH = 80;                    // K rows: 64 B + 16 (conflict-free 16-byte fragment reads)
-  static constexpr int OFF_K = 0;                       // [32 keys][80 B]
-  static constexpr int OFF_VLO = GT * K_PITCH;          // [32 keys][16 channels] 16-bit: channels 0..15
+  static constexpr int OFF_K = 0;                       // [64 keys][4 chunks of 16 B], chunk c of key n at position c ^ ((n >> 2) & 3)
+  static constexpr int OFF_VLO = GT * 64;               // [64 keys][16 channels] 16-bit: channels 0..15
   static constexpr int OFF_VHI = OFF_VLO + GT * 32;     // channels 16..31
-  static constexpr int OFF_W = OFF_VHI + GT * 32;       // [32 keys] 2 dwords: packed weights of column x | x + 1, each (y, y + 1)
-  static constexpr int OFF_OFF = OFF_W + GT * 8;        // [32 keys] LDS byte address of tap (y, x) for BEV row 0
-  static constexpr int OFF_CT = OFF_OFF + GT * 4;       // u32x4: flags (bit 2: done), live-key mask, entries of the fill list, 0
+  static constexpr int OFF_W = OFF_VHI + GT * 32;       // [64 keys] 2 dwords: packed weights of column x | x + 1, each (y, y + 1)
+  static constexpr int OFF_OFF = OFF_W + GT * 8;        // [64 keys] LDS byte address of tap (y, x) for BEV row 0
+  static constexpr int OFF_CT = OFF_OFF + GT * 4;       // u32x4: flags (bit 2: done), live keys 0..31, 32..63, entries of the fill list
   static constexpr int OFF_FD = OFF_CT + 16;            // fill list of the NEXT emission's window: [WIN_COLS] (column, first row)
   static constexpr int BUF = OFF_FD + WIN_COLS * 8;
   static constexpr int WIN = WIN_COLS * PITCH * 4;
@@ -71,12 +72,19 @@ struct LdsG {
 };
 static_assert(LdsG::BUF % 16 == 0 && LdsG::WIN % 16 == 0, "16-byte aligned LDS blocks");
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight
-// (s_waitcnt vmcnt(0)), which put the memory latency of the producer's prefetches -- issued just before the barrier
-// on purpose -- on every emission's critical path.
+// (s_waitcnt vmcnt(0)): the prefetches that are meant to cross the barrier.
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-constexpr float RAISE = 40.0f;   // binades a logit may exceed the reference before the reference moves
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr float RAISE = 40.0f;   // EXACT: binades a logit may exceed the reference before the reference moves
 
-template <int PREC, int NB, bool EXACT>
+typedef const char __attribute__((address_space(1)))* gptr_t;
+typedef char __attribute__((address_space(3)))* lptr_t;
+// 64 lanes x 16 bytes, global (per-lane address) -> LDS (base + 16 lane), no registers
+__device__ __forceinline__ void glds16(const char* src, char* lds_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_base, 16, 0, 0);
+}
+
+template <int PREC, int NB, bool EXACT, bool DMA>
 __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
     bevr_attn_desc d, const char* __restrict__ Q, const char* __restrict__ K, const char* __restrict__ V,
     const char* __restrict__ key_ws, const uint32_t* __restrict__ table_pk, const float* __restrict__ mref,
@@ -101,88 +109,73 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
   const int rows_q = nblk * QB;
   const float rx = (float)(d.Wt - 1) / (2.0f * (float)(d.S - 1));
   const float jrx = (float)j * rx;
-  typedef char __attribute__((address_space(3)))* lds_cp;
-  const unsigned smem_base = (unsigned)(size_t)(lds_cp)smem;     // window addresses are handed over as LDS addresses
+  const unsigned smem_base = (unsigned)(size_t)(lptr_t)smem;     // window addresses are handed over as LDS addresses
 
   // ---- the window fill, shared by ALL waves: entry c of a fill list = (padded table column, first table row) of window
-  // column c.  Entries [0, FILL_P) are the producer's, entry FILL_P + w row-block wave w's: loaded when an emission
-  // starts and stored when it ends (the L2 latency hides behind the emission's matrix work; the row-block waves have
-  // no registers to spare for more than one column).  Entries past those (one window in ten) are copied in place.
+  // column c; wave w copies the entries w, w + n_wave, ...  One column = PITCH dwords = 63 lanes x 16 bytes, global -> LDS
+  // directly (no registers): issued when an emission starts, waited for before its closing barrier -- the L2 latency hides
+  // behind the emission's matrix work.  A table shorter than a window column (small problems) goes through registers.
   const char* tbl = reinterpret_cast<const char*>(table_pk + (size_t)hd * d.Wp * d.Hp);
-  constexpr int FILL_P = 8;
-  const int fill_ov = FILL_P + n_wave - 1;      // entries with an owner
-  auto load_col_at = [&](int xc, int r0) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (lane < PITCH / 4) {
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto fill_one = [&](char* win, int c, int xc, int r0) {      // xc, r0: uniform
+    if (lane >= PITCH / 4) return;
+    if constexpr (DMA) {       // the launcher's choice: the table is at least a window column tall
+      // scalar base + this lane's 16 bytes: no vector address arithmetic next to the accumulators
+      const char* sbase = tbl + ((size_t)__builtin_amdgcn_readfirstlane(xc) * d.Hp + __builtin_amdgcn_readfirstlane(r0)) * 4;
+      glds16(sbase + lane16, win + (c * PITCH) * 4);
+    } else {
       const int rr = r0 + 4 * lane;
       const char* src = tbl + ((size_t)xc * d.Hp + rr) * 4;
-      if (rr + 4 <= d.Hp) {
-        v = *reinterpret_cast<const u32x4*>(src);
-      } else {       // the end of a table shorter than a window column
+      u32x4 v = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (rr + k < d.Hp) v[k] = *reinterpret_cast<const uint32_t*>(src + 4 * k);
-      }
+      for (int k = 0; k < 4; ++k)
+        if (rr + k < d.Hp) v[k] = *reinterpret_cast<const uint32_t*>(src + 4 * k);
+      *reinterpret_cast<u32x4*>(win + (c * PITCH) * 4 + lane * 16) = v;
     }
-    return v;
   };
-  auto load_col = [&](const int* fd, int c) { return load_col_at(fd[2 * c], fd[2 * c + 1]); };
-  auto store_col = [&](char* win, int c, const u32x4& v) {
-    if (lane < PITCH / 4) *reinterpret_cast<u32x4*>(win + (c * PITCH) * 4 + lane * 16) = v;
-  };
-  auto fill_rest = [&](const int* fd, char* win, int nfill, int first) {
-    for (int c = first; c < nfill; c += n_wave) store_col(win, c, load_col(fd, c));
+  auto fill_share = [&](const int* fd, char* win, int nfill) {
+    for (int c = wave; c < nfill; c += n_wave) fill_one(win, c, fd[2 * c], fd[2 * c + 1]);
   };
 
   if (wave == n_wave - 1) {
     // ---- producer ------------------------------------------------------------------------------------------
-#if BEVR_VARIANT != 1
     __builtin_amdgcn_s_setprio(3);
-#endif
     const int pg = prob * d.groups + hd / (d.heads / d.groups);
     const KeyW* kws = reinterpret_cast<const KeyW*>(key_ws) + (size_t)pg * d.Np;
     const StepBox* box = reinterpret_cast<const StepBox*>(key_ws + key_ws_box_offset(d)) + (size_t)pg * (d.Np / 32);
     const char* Kp = K + (size_t)ph * d.Np * 64;
     const char* Vp = V + (size_t)ph * d.Np * 64;
-    const int n_tiles = d.Np / GT;
-    const int kl = lane & 31, half = lane >> 5;
+    const int n_steps = d.Np / GT;
 
-    // One emission: the keys `sel` of a tile, their rows, weights and window offsets, and the fill list of its window
-    // (this lane's entry).  The producer runs ONE emission ahead: emission e + 1 is described before e is staged, so that
-    // the fill list of window e + 1 travels with emission e.
+    // One emission: the keys `sel` of a 64-key step, their weights and window addresses, and the fill list of its window
+    // (this lane's entry).  The producer DESCRIBES one emission ahead of the one it stages (the fill list of window e + 1
+    // travels with emission e) and stages one emission ahead of the row-block waves.
     struct Em {
-      unsigned sel;
-      int nfill, fd_xc, fd_r0, koff;
+      unsigned long long sel;
+      int step, nfill, fd_xc, fd_r0, koff;
       u32x2 w;
     };
-    u32x4 kr[2], vr[2];      // K / V rows of the emission described last: loaded then, staged one emission later
-    // the tile the generator is in (records prefetched one tile ahead)
-    int tile = -1;
-    unsigned rem = 0u;
+    int step = -1;
+    unsigned long long rem = 0ull;
+    const int kl = lane & (GT - 1);      // this lane's key of a step (GT = 32: the upper half wave duplicates the lower)
+    const bool klane = lane < GT;
     KeyW kw_n = kws[kl];
-    StepBox sb_n = box[0];
-    auto fetch_kv = [&](int t) {
-      const size_t n = (size_t)t * GT + kl;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        kr[i] = *reinterpret_cast<const u32x4*>(Kp + n * 64 + 32 * half + 16 * i);
-        vr[i] = *reinterpret_cast<const u32x4*>(Vp + n * 64 + 32 * half + 16 * i);
-      }
-    };
+    StepBox sb0_n = box[0], sb1_n = box[NT - 1];
     int ar = 0, xc = 0, x0 = 0, a0w = 0, cols = 0;
     bool fits = false;
     u32x2 w_t = {0u, 0u};
     auto advance = [&](Em& em) -> bool {
-      while (rem == 0u) {      // on to the next tile with live keys
-        if (++tile >= n_tiles) return false;
+      while (rem == 0ull) {      // on to the next step with live keys
+        if (++step >= n_steps) return false;
         const KeyW kw = kw_n;
-        const StepBox sb = sb_n;
-        if (tile + 1 < n_tiles) {
-          kw_n = kws[(size_t)(tile + 1) * GT + kl];
-          sb_n = box[tile + 1];
+        const StepBox sb = box_union(sb0_n, sb1_n);
+        if (step + 1 < n_steps) {
+          kw_n = kws[(size_t)(step + 1) * GT + kl];
+          sb0_n = box[NT * (step + 1)];
+          sb1_n = box[NT * (step + 1) + NT - 1];
         }
-        if (sb.amax < sb.amin) continue;               // a tile of padding only
-        const bool live = tile * GT + kl < d.N;
+        if (sb.amax < sb.amin) continue;               // a step of padding only
+        const bool live = klane && step * GT + kl < d.N;
         ar = (kw.aoff >> 3) - d.x_off * d.Hp;          // padded table row of tap (y, .) for BEV row 0
         const float tx = jrx + kw.b;
         const float xf = floorf(tx);
@@ -190,16 +183,16 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
         const float fx = tx - xf, fy = kw.fy;
         w_t[0] = Half<PREC>::pack2((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy);
         w_t[1] = Half<PREC>::pack2(fx * (1.0f - fy), fx * fy);
-        // the tile's box: columns [x0, x1], rows [a0, a0 + rspan)
+        // the step's box: columns [x0, x1], rows [a0, a0 + rspan)
         x0 = (int)floorf(jrx + sb.bmin) + d.x_off;
         const int x1 = (int)floorf(jrx + sb.bmax) + 1 + d.x_off;
         cols = x1 - x0 + 1;
         fits = cols <= WIN_COLS && sb.amax - sb.amin + rows_q + 1 <= PITCH;
         a0w = max(0, min(sb.amin + d.y_off, d.Hp - PITCH));
-        rem = (unsigned)__ballot(live && half == 0);
+        rem = __ballot(live);
       }
       em.w = w_t;
-      fetch_kv(tile);
+      em.step = step;
       if (fits) {
         em.sel = rem;
         em.koff = ((xc - x0) * PITCH + (ar - a0w)) * 4;
@@ -207,18 +200,17 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
         em.fd_xc = x0 + lane;
         em.fd_r0 = a0w;
       } else {
-        // the first STRIP_KEYS remaining keys, one two-column strip each: entry 2 rank + {0, 1}
-        const int rank = __builtin_popcount(rem & ((1u << kl) - 1u));
-        const bool mine = (rem >> kl & 1u) && rank < STRIP_KEYS;
-        em.sel = (unsigned)__ballot(mine && half == 0);
+        // the first STRIP_KEYS remaining keys, one two-column strip each: entries 2 rank + {0, 1}
+        const int rank = __builtin_popcountll(rem & ((1ull << kl) - 1ull));
+        const bool mine = klane && (rem >> kl & 1ull) && rank < STRIP_KEYS;
+        em.sel = __ballot(mine);
         const int akw = max(0, min(ar, d.Hp - PITCH));
         em.koff = (2 * rank * PITCH + (ar - akw)) * 4;
-        em.nfill = 2 * __builtin_popcount(em.sel);
+        em.nfill = 2 * __builtin_popcountll(em.sel);
         // lane 2 r + c holds the entry of the key with rank r: fetch that key's (xc, akw)
-        const unsigned long long mm = __ballot(mine && half == 0);
-        int src = 0;       // lane of the key with rank (lane >> 1)
+        int src = 0;
         {
-          unsigned long long t = mm;
+          unsigned long long t = em.sel;
           for (int k = 0; k < (lane >> 1) && t; ++k) t &= t - 1;
           src = t ? __builtin_ctzll(t) : 0;
         }
@@ -228,87 +220,85 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
       rem &= ~em.sel;
       return true;
     };
-    // staging of emission e, in two parts: the keys' operands (before the next emission is described: its K / V rows
-    // take over the registers) and the control record with the fill list of the next window
-    auto stage_keys = [&](const Em& em, int e) {
+    // Staging of emission e (one emission ahead of its use).  K / V rows go global -> LDS directly (8 x 1 KB, no
+    // registers): K with its 16-byte chunks XOR-swizzled (conflict-free fragment reads of unpadded 64-byte rows), V as two
+    // [key][16 channel] images.
+    auto stage = [&](const Em& em, int e, const Em* nxt) {
       char* bb = smem + (e & 1) * L::BUF;
-      // K, V: lane = (key, 32-byte half of the row)
-      *reinterpret_cast<u32x4*>(bb + L::OFF_K + kl * L::K_PITCH + 32 * half) = kr[0];
-      *reinterpret_cast<u32x4*>(bb + L::OFF_K + kl * L::K_PITCH + 32 * half + 16) = kr[1];
-      char* vimg = bb + (half ? L::OFF_VHI : L::OFF_VLO) + kl * 32;
-      *reinterpret_cast<u32x4*>(vimg) = vr[0];
-      *reinterpret_cast<u32x4*>(vimg + 16) = vr[1];
-      if (half == 0) {
+      const size_t n0 = (size_t)em.step * GT;
+#pragma unroll
+      for (int i = 0; i < GT / 16; ++i) {      // keys 16 i .. 16 i + 15: lane = (key, position)
+        const int n = 16 * i + (lane >> 2), c = (lane & 3) ^ ((n >> 2) & 3);
+        glds16(Kp + (n0 + n) * 64 + 16 * c, bb + L::OFF_K + i * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {           // keys 32 i .. 32 i + 31: lane = (key, 16-byte half of the 16 channels)
+        const int n = 32 * i + (lane >> 1);
+        glds16(Vp + (n0 + n) * 64 + 16 * (lane & 1), bb + L::OFF_VLO + i * 1024);
+        glds16(Vp + (n0 + n) * 64 + 32 + 16 * (lane & 1), bb + L::OFF_VHI + i * 1024);
+      }
+      if (klane) {
         *reinterpret_cast<u32x2*>(bb + L::OFF_W + kl * 8) = em.w;
         // a key outside the emission: any address inside the window (its logit is masked)
-        const bool in = em.sel >> kl & 1u;
+        const bool in = em.sel >> kl & 1ull;
         *reinterpret_cast<unsigned*>(bb + L::OFF_OFF + kl * 4) = smem_base + L::OFF_WIN + (e & 1) * L::WIN + (in ? em.koff : 0);
       }
-    };
-    auto stage_ct = [&](const Em& em, int e, const Em* nxt) {
-      char* bb = smem + (e & 1) * L::BUF;
       if (nxt && lane < nxt->nfill) {
         int* fd = reinterpret_cast<int*>(bb + L::OFF_FD);
         fd[2 * lane] = nxt->fd_xc;
         fd[2 * lane + 1] = nxt->fd_r0;
       }
-      if (lane == 0) *reinterpret_cast<u32x4*>(bb + L::OFF_CT) = u32x4{0u, em.sel, nxt ? (unsigned)nxt->nfill : 0u, 0u};
+      if (lane == 0)
+        *reinterpret_cast<u32x4*>(bb + L::OFF_CT) =
+            u32x4{0u, (unsigned)em.sel, (unsigned)(em.sel >> 32), nxt ? (unsigned)nxt->nfill : 0u};
     };
 
     Em cur, nxt;
     advance(cur);       // N >= 1: there is a first emission
-    {                   // prologue: the fill list of window 0 travels in buffer 1
+    bool more = advance(nxt);
+    {                   // prologue: the fill list of window 0 travels in buffer 1; emission 0 is staged
       int* fd = reinterpret_cast<int*>(smem + L::BUF + L::OFF_FD);
       if (lane < cur.nfill) {
         fd[2 * lane] = cur.fd_xc;
         fd[2 * lane + 1] = cur.fd_r0;
       }
-      if (lane == 0) *reinterpret_cast<u32x4*>(smem + L::BUF + L::OFF_CT) = u32x4{0u, 0u, (unsigned)cur.nfill, 0u};
+      if (lane == 0) *reinterpret_cast<u32x4*>(smem + L::BUF + L::OFF_CT) = u32x4{0u, 0u, 0u, (unsigned)cur.nfill};
       barrier_lds();
-      fill_rest(fd, smem + L::OFF_WIN, cur.nfill, wave);
+      fill_share(fd, smem + L::OFF_WIN, cur.nfill);
+      stage(cur, 0, more ? &nxt : nullptr);
+      wait_vm0();
     }
 #ifdef BEVR_GPROF
     unsigned long long gacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // iteration e: the row-block waves work on emission e; the producer stages emission e + 1 (`nxt`), fills its share of
+    // window e + 1 and describes emission e + 2
     for (int e = 0;; ++e) {
       GPROF(p0);
-      stage_keys(cur, e);      // waits for the K / V rows of this emission only: nothing younger is in flight yet
+      barrier_lds();      // emission e and window e are complete; buffer / window (e + 1) & 1 are free
       GPROF(p1);
-      // the producer's columns of window e (window 0 is the prologue's); the fill list comes out of the lanes' registers
-      const int nf = e > 0 ? cur.nfill : 0;
-      u32x4 fv[FILL_P];
-#pragma unroll
-      for (int k = 0; k < FILL_P; ++k)
-        if (k < nf) fv[k] = load_col_at(__builtin_amdgcn_readlane(cur.fd_xc, k), __builtin_amdgcn_readlane(cur.fd_r0, k));
-      GPROF(p1b);
-      const bool more = advance(nxt);
-      stage_ct(cur, e, more ? &nxt : nullptr);
-      GPROF(p2);
-      {
-        char* wcur = smem + L::OFF_WIN + (e & 1) * L::WIN;
-#pragma unroll
-        for (int k = 0; k < FILL_P; ++k)
-          if (k < nf) store_col(wcur, k, fv[k]);
-        GPROF(p3a);
-        GPROF_ADD(2, p3a - p2);
-        for (int c = fill_ov + wave; c < nf; c += n_wave)
-          store_col(wcur, c, load_col_at(__builtin_amdgcn_readlane(cur.fd_xc, c), __builtin_amdgcn_readlane(cur.fd_r0, c)));
-      }
-      GPROF(p3);
-      barrier_lds();
-      GPROF(p4);
-      GPROF_ADD(0, p1 - p0);
-      GPROF_ADD(6, p1b - p1);
-      GPROF_ADD(1, p2 - p1b);
-      GPROF_ADD(3, p3 - p2);
-      GPROF_ADD(4, p4 - p3);
-      GPROF_ADD(5, 1);
       if (!more) {
         if (lane == 0) *reinterpret_cast<u32x4*>(smem + ((e + 1) & 1) * L::BUF + L::OFF_CT) = u32x4{4u, 0u, 0u, 0u};
         barrier_lds();
         break;
       }
-      cur = nxt;
+      cur = nxt;          // emission e + 1
+      {                   // the producer's columns of window e + 1; the fill list comes out of the lanes' registers
+        char* wn = smem + L::OFF_WIN + ((e + 1) & 1) * L::WIN;
+        for (int c = wave; c < cur.nfill; c += n_wave)
+          fill_one(wn, c, __builtin_amdgcn_readlane(cur.fd_xc, c), __builtin_amdgcn_readlane(cur.fd_r0, c));
+      }
+      GPROF(p2);
+      more = advance(nxt);
+      stage(cur, e + 1, more ? &nxt : nullptr);
+      GPROF(p3);
+      wait_vm0();         // the K / V rows and the window columns have landed
+      GPROF(p4);
+      GPROF_ADD(4, p1 - p0);
+      GPROF_ADD(6, p2 - p1);
+      GPROF_ADD(1, p3 - p2);
+      GPROF_ADD(3, p4 - p3);
+      GPROF_ADD(5, 1);
     }
 #ifdef BEVR_GPROF
     if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof_gather[i], gacc[i]);
@@ -322,8 +312,9 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
   bf16x8 qf[NB];          // B operand of QK^T: Q[q][8 kg ..]
   f32x4 o_lo[NB], o_hi[NB];
   f32x4 negm[NB];         // minus the softmax reference: the accumulator start of every logit product
-  f32x2 lsum[NB];         // row sum, two partial sums (packed adds)
-  float pmx[NB];          // an upper bound of the largest weight (a partial sum of four)
+  f32x4 lacc[NB];         // row sum: a product of the ROUNDED weights with a ones operand (every register the same sum):
+                          // O / l is then exact where one key dominates -- the backward's delta = dO . O relies on it
+  float pmx[NB];          // the largest weight
   unsigned qoff[NB];      // byte offset of the lane's BEV row in a window column
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -335,16 +326,20 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
     o_lo[nb] = o_hi[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float mr = EXACT ? 0.f : mref[(size_t)ph * Mp + mcol];
     negm[nb] = f32x4{-mr, -mr, -mr, -mr};
-    lsum[nb] = f32x2{0.f, 0.f};
+    lacc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     pmx[nb] = 0.f;
   }
+  const uint32_t one2 = Half<PREC>::pack2(1.0f, 1.0f);
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{one2, one2, one2, one2});
   const int t_off = (4 * kg + (li >> 2)) * 32 + (lane & 3) * 8;      // transposed reads of a [key][16] image
+  const int k_off = li * 64 + 16 * (kg ^ (li >> 2));                 // this lane's K fragment in a 16-key block
   typedef const uint32_t __attribute__((address_space(3)))* lds_u32p;
 
   {   // prologue: window 0
     barrier_lds();
-    const int nf0 = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u32x4*>(smem + L::BUF + L::OFF_CT)[0][2]);
-    fill_rest(reinterpret_cast<const int*>(smem + L::BUF + L::OFF_FD), smem + L::OFF_WIN, nf0, wave);
+    const int nf0 = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<const u32x4*>(smem + L::BUF + L::OFF_CT)[0][3]);
+    fill_share(reinterpret_cast<const int*>(smem + L::BUF + L::OFF_FD), smem + L::OFF_WIN, nf0);
+    wait_vm0();
   }
   bool first = true;      // EXACT only
 #ifdef BEVR_GPROF
@@ -364,98 +359,93 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
     const char* bb = smem + (e & 1) * L::BUF;
     const u32x4 ct = *reinterpret_cast<const u32x4*>(bb + L::OFF_CT);
     if (__builtin_amdgcn_readfirstlane((int)ct[0]) & 4) break;
-    const unsigned livem = (unsigned)__builtin_amdgcn_readfirstlane((int)ct[1]);
-    // this wave's share of the next window: loads now, stores after the emission's work
-    const int nfill = __builtin_amdgcn_readfirstlane((int)ct[2]);
-    const int* fd = reinterpret_cast<const int*>(bb + L::OFF_FD);
-    u32x4 fv = {0u, 0u, 0u, 0u};
-    if (FILL_P + wave < nfill) fv = load_col(fd, FILL_P + wave);
-    const bf16x8 vlo = lds_tr8(bb + L::OFF_VLO + t_off, 512);
-    const bf16x8 vhi = lds_tr8(bb + L::OFF_VHI + t_off, 512);
-    u32x4 pw[NB];          // the tile's weights, packed: the B operand of PV
+    // this wave's share of the next window: in flight during the emission's work
+    fill_share(reinterpret_cast<const int*>(bb + L::OFF_FD), smem + L::OFF_WIN + ((e + 1) & 1) * L::WIN,
+               __builtin_amdgcn_readfirstlane((int)ct[3]));
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+      const unsigned livem = (unsigned)__builtin_amdgcn_readfirstlane((int)(t ? ct[2] : ct[1]));
+      // (no shortcut for a tile or sub-tile without live keys -- strip emissions only: its keys are masked like any
+      // other; every accumulator update stays unconditional, which keeps the accumulators in place)
+      const bf16x8 vlo = lds_tr8(bb + L::OFF_VLO + t * 1024 + t_off, 512);
+      const bf16x8 vhi = lds_tr8(bb + L::OFF_VHI + t * 1024 + t_off, 512);
+      u32x4 pw[NB];          // the tile's weights, packed: the B operand of PV
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      if ((livem >> (16 * s2) & 0xffffu) == 0u) {      // uniform: no key of this sub-tile in the emission
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int kb = 32 * t + 16 * s2;                 // first key of the sub-tile
+        const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bb + L::OFF_K + kb * 64 + k_off));
+        // W: lane (key li, k-group kg) holds the slots of keys 8 m + 2 kg + {0, 1} of product m: its own key's weights or 0
+        const u32x2 w4 = *reinterpret_cast<const u32x2*>(bb + L::OFF_W + (kb + li) * 8);
+        const bool m00 = li == 2 * kg, m01 = li == 2 * kg + 1, m10 = li == 8 + 2 * kg, m11 = li == 9 + 2 * kg;
+        const u32x4 a0 = {m00 ? w4[0] : 0u, m00 ? w4[1] : 0u, m01 ? w4[0] : 0u, m01 ? w4[1] : 0u};
+        const u32x4 a1 = {m10 ? w4[0] : 0u, m10 ? w4[1] : 0u, m11 ? w4[0] : 0u, m11 ? w4[1] : 0u};
+        const bf16x8 wa0 = __builtin_bit_cast(bf16x8, a0), wa1 = __builtin_bit_cast(bf16x8, a1);
+        // window addresses of keys 2 kg, 2 kg + 1 (first bias product) and 8 + 2 kg, 9 + 2 kg (second)
+        const u32x2 oc0 = *reinterpret_cast<const u32x2*>(bb + L::OFF_OFF + (kb + 2 * kg) * 4);
+        const u32x2 oc1 = *reinterpret_cast<const u32x2*>(bb + L::OFF_OFF + (kb + 8 + 2 * kg) * 4);
+        // both row blocks' logit chains first (independent: their matrix products interleave), then the weights.  A wave
+        // whose second block lies past the column computes it on the clamped rows and drops it in the epilogue.
+        f32x4 sv[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) pw[nb][2 * s2] = pw[nb][2 * s2 + 1] = 0u;
-        continue;
-      }
-      const bf16x8 kf = __builtin_bit_cast(
-          bf16x8, *reinterpret_cast<const u32x4*>(bb + L::OFF_K + (16 * s2 + li) * L::K_PITCH + 16 * kg));
-      // W: lane (key li, k-group kg) holds the slots of keys 8 m + 2 kg + {0, 1} of product m: its own key's weights or 0
-      const u32x2 w4 = *reinterpret_cast<const u32x2*>(bb + L::OFF_W + (16 * s2 + li) * 8);
-      const bool m00 = li == 2 * kg, m01 = li == 2 * kg + 1, m10 = li == 8 + 2 * kg, m11 = li == 9 + 2 * kg;
-      const u32x4 a0 = {m00 ? w4[0] : 0u, m00 ? w4[1] : 0u, m01 ? w4[0] : 0u, m01 ? w4[1] : 0u};
-      const u32x4 a1 = {m10 ? w4[0] : 0u, m10 ? w4[1] : 0u, m11 ? w4[0] : 0u, m11 ? w4[1] : 0u};
-      const bf16x8 wa0 = __builtin_bit_cast(bf16x8, a0), wa1 = __builtin_bit_cast(bf16x8, a1);
-      // window addresses of keys 2 kg, 2 kg + 1 (first bias product) and 8 + 2 kg, 9 + 2 kg (second)
-      const u32x2 oc0 = *reinterpret_cast<const u32x2*>(bb + L::OFF_OFF + (16 * s2 + 2 * kg) * 4);
-      const u32x2 oc1 = *reinterpret_cast<const u32x2*>(bb + L::OFF_OFF + (16 * s2 + 8 + 2 * kg) * 4);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        if (NB > 1 && blk0 + nb >= nblk) continue;
-        u32x4 g0, g1;
-        {
+        for (int nb = 0; nb < NB; ++nb) {
+          u32x4 g0, g1;
           const lds_u32p p0 = (lds_u32p)(uintptr_t)(oc0[0] + qoff[nb]), p1 = (lds_u32p)(uintptr_t)(oc0[1] + qoff[nb]);
           const lds_u32p p2 = (lds_u32p)(uintptr_t)(oc1[0] + qoff[nb]), p3 = (lds_u32p)(uintptr_t)(oc1[1] + qoff[nb]);
           g0[0] = p0[0]; g0[1] = p0[PITCH]; g0[2] = p1[0]; g0[3] = p1[PITCH];
           g1[0] = p2[0]; g1[1] = p2[PITCH]; g1[2] = p3[0]; g1[3] = p3[PITCH];
+          sv[nb] = mfma16<PREC>(kf, qf[nb], negm[nb]);
+          sv[nb] = mfma16<PREC>(wa0, __builtin_bit_cast(bf16x8, g0), sv[nb]);
+          sv[nb] = mfma16<PREC>(wa1, __builtin_bit_cast(bf16x8, g1), sv[nb]);
         }
-        f32x4 sv = mfma16<PREC>(kf, qf[nb], negm[nb]);
-        sv = mfma16<PREC>(wa0, __builtin_bit_cast(bf16x8, g0), sv);
-        sv = mfma16<PREC>(wa1, __builtin_bit_cast(bf16x8, g1), sv);
         if ((livem >> (16 * s2) & 0xffffu) != 0xffffu) {      // uniform: padding keys, or a strip emission
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (!(livem >> (16 * s2 + 4 * kg + r) & 1u)) sv[r] = -1.0e30f;
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (!(livem >> (16 * s2 + 4 * kg + r) & 1u)) sv[nb][r] = -1.0e30f;
         }
-        if constexpr (EXACT) {
-          // online reference: the maximum of the row's first keys, raised (with a rescale) when a later logit exceeds it
-          const float tm = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-          if (first || __any(tm > RAISE)) {
-            float tx = fmaxf(tm, __shfl_xor(tm, 16));
-            tx = fmaxf(tx, __shfl_xor(tx, 32));
-            const float delta = first ? tx : fmaxf(tx, 0.f);
-            const float al = first ? 1.0f : fast_exp2(-delta);
-            negm[nb] -= delta;
-            o_lo[nb] *= al;
-            o_hi[nb] *= al;
-            lsum[nb] *= al;
-            pmx[nb] *= al;
-            sv -= delta;
-            if (s2 == 1) {       // the first sub-tile's weights of this tile are in pw already
-              pw[nb][0] = Half<PREC>::pack2(Half<PREC>::lo(pw[nb][0]) * al, Half<PREC>::hi(pw[nb][0]) * al);
-              pw[nb][1] = Half<PREC>::pack2(Half<PREC>::lo(pw[nb][1]) * al, Half<PREC>::hi(pw[nb][1]) * al);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          if constexpr (EXACT) {
+            // online reference: the maximum of the row's first keys, raised (with a rescale) when a later logit exceeds it
+            const float tm = fmaxf(fmaxf(sv[nb][0], sv[nb][1]), fmaxf(sv[nb][2], sv[nb][3]));
+            if (first || __any(tm > RAISE)) {
+              float tx = fmaxf(tm, __shfl_xor(tm, 16));
+              tx = fmaxf(tx, __shfl_xor(tx, 32));
+              const float delta = first ? tx : fmaxf(tx, 0.f);
+              const float al = first ? 1.0f : fast_exp2(-delta);
+              negm[nb] -= delta;
+              o_lo[nb] *= al;
+              o_hi[nb] *= al;
+              lacc[nb] *= al;
+              pmx[nb] *= al;
+              sv[nb] -= delta;
+              if (s2 == 1) {       // the first sub-tile's weights of this tile are in pw already
+                pw[nb][0] = Half<PREC>::pack2(Half<PREC>::lo(pw[nb][0]) * al, Half<PREC>::hi(pw[nb][0]) * al);
+                pw[nb][1] = Half<PREC>::pack2(Half<PREC>::lo(pw[nb][1]) * al, Half<PREC>::hi(pw[nb][1]) * al);
+              }
             }
           }
+          const f32x2 pa = {fast_exp2(sv[nb][0]), fast_exp2(sv[nb][1])}, pb2 = {fast_exp2(sv[nb][2]), fast_exp2(sv[nb][3])};
+          pw[nb][2 * s2] = Half<PREC>::pack2(pa[0], pa[1]);
+          pw[nb][2 * s2 + 1] = Half<PREC>::pack2(pb2[0], pb2[1]);
+          pmx[nb] = fmaxf(fmaxf(fmaxf(pmx[nb], pa[0]), pa[1]), fmaxf(pb2[0], pb2[1]));
         }
-        const f32x2 pa = {fast_exp2(sv[0]), fast_exp2(sv[1])}, pb2 = {fast_exp2(sv[2]), fast_exp2(sv[3])};
-        pw[nb][2 * s2] = Half<PREC>::pack2(pa[0], pa[1]);
-        pw[nb][2 * s2 + 1] = Half<PREC>::pack2(pb2[0], pb2[1]);
-        const f32x2 ps = pa + pb2;
-        lsum[nb] += ps;
-        pmx[nb] = fmaxf(fmaxf(pmx[nb], ps[0]), ps[1]);
+        if constexpr (EXACT) first = false;
       }
-      if constexpr (EXACT) first = false;
-    }
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      if (NB > 1 && blk0 + nb >= nblk) continue;
-      const bf16x8 pb = __builtin_bit_cast(bf16x8, pw[nb]);
-      o_lo[nb] = mfma16<PREC>(vlo, pb, o_lo[nb]);
-      o_hi[nb] = mfma16<PREC>(vhi, pb, o_hi[nb]);
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, pw[nb]);
+        o_lo[nb] = mfma16<PREC>(vlo, pb, o_lo[nb]);
+        o_hi[nb] = mfma16<PREC>(vhi, pb, o_hi[nb]);
+        lacc[nb] = mfma16<PREC>(ones, pb, lacc[nb]);
+      }
     }
-    {
-      GPROF(c2);
-      GPROF_ADD(1, c2 - c1);
-      char* wnext = smem + L::OFF_WIN + ((e + 1) & 1) * L::WIN;
-      if (FILL_P + wave < nfill) store_col(wnext, FILL_P + wave, fv);
-      GPROF(c3);
-      GPROF_ADD(2, c3 - c2);
-      fill_rest(fd, wnext, nfill, fill_ov + wave);
-      GPROF(c4);
-      GPROF_ADD(3, c4 - c3);
-    }
+    GPROF(c2);
+    GPROF_ADD(1, c2 - c1);
+    wait_vm0();
+    GPROF(c3);
+    GPROF_ADD(2, c3 - c2);
   }
 #ifdef BEVR_GPROF
   if (lane == 0 && (wave == 0 || wave == 3)) for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof_gather[8 + (wave ? 8 : 0) + i], gacc[i]);
@@ -466,9 +456,7 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     if (blk0 + nb >= nblk) continue;
-    float l = lsum[nb][0] + lsum[nb][1];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = lacc[nb][0];
     float pm = fmaxf(pmx[nb], __shfl_xor(pmx[nb], 16));
     pm = fmaxf(pm, __shfl_xor(pm, 32));
     const int row = (blk0 + nb) * QB + li;
@@ -485,7 +473,7 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
       const int n_copy = (blk0 + nb == nblk - 1) ? (d.Sp - row + QB - 1) / QB : 1;
       for (int k = 0; k < n_copy; ++k) {
         LSE[mq + k * QB] = lg - negm[nb][0];
-        // plane 1: log2 of an upper bound of the row's largest softmax weight (a partial sum of two weights)
+        // plane 1: log2 of the row's largest softmax weight
         LSE[(size_t)n_ph * Mp + mq + k * QB] = __log2f(pm) - lg;
       }
     }
@@ -507,12 +495,19 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* V,
   const int nb = nblk <= 7 ? 1 : 2;      // row blocks per wave: at most 7 row-block waves + the producer
   const int n_cw = (nblk + nb - 1) / nb;
   const dim3 block(64 * (n_cw + 1));
-#define BEVR_GATHER_LAUNCH(NB_, EX_)                                                                                 \
-  hipLaunchKernelGGL((attn_gather_fwd_kernel<PREC, NB_, EX_>), dim3(grid), block, L::TOTAL, st, d, (const char*)Q,  \
-                     (const char*)K, (const char*)V, (const char*)key_ws, (const uint32_t*)table_pk, mref, O, LSE, flags)
+#define BEVR_GATHER_LAUNCH(NB_, EX_, DMA_)                                                                           \
+  hipLaunchKernelGGL((attn_gather_fwd_kernel<PREC, NB_, EX_, DMA_>), dim3(grid), block, L::TOTAL, st, d,            \
+                     (const char*)Q, (const char*)K, (const char*)V, (const char*)key_ws, (const uint32_t*)table_pk, \
+                     mref, O, LSE, flags)
+  const bool dma = d.Hp >= PITCH;        // else (small problems): the window columns are copied through registers
   for (int ex = 0; ex < 2; ++ex) {       // static reference, then the exact pass over the flagged columns
-    if (nb == 1) { if (ex) BEVR_GATHER_LAUNCH(1, true); else BEVR_GATHER_LAUNCH(1, false); }
-    else { if (ex) BEVR_GATHER_LAUNCH(2, true); else BEVR_GATHER_LAUNCH(2, false); }
+    if (nb == 1) {
+      if (dma) { if (ex) BEVR_GATHER_LAUNCH(1, true, true); else BEVR_GATHER_LAUNCH(1, false, true); }
+      else { if (ex) BEVR_GATHER_LAUNCH(1, true, false); else BEVR_GATHER_LAUNCH(1, false, false); }
+    } else {
+      if (dma) { if (ex) BEVR_GATHER_LAUNCH(2, true, true); else BEVR_GATHER_LAUNCH(2, false, true); }
+      else { if (ex) BEVR_GATHER_LAUNCH(2, true, false); else BEVR_GATHER_LAUNCH(2, false, false); }
+    }
     const int rc = (int)hipGetLastError();
     if (rc) return rc;
   }

@@ -372,10 +372,11 @@ class _Seg:
     geom: AttnGeom
 
 
-def gather_supported(precision) -> bool:
-    """Do scattered keys run on the gather kernels (csrc/attn_gather_*.hip: bias on the matrix cores, table taps
-    gathered from L2) instead of the region kernels?  bf16 operands only; BEVR_GATHER=0 turns them off (A/B timing)."""
-    return precision == _lib.PREC_BF16 and os.environ.get("BEVR_GATHER", "0") == "1"
+def gather_supported(precision, S) -> bool:
+    """Does the forward over scattered keys run on the gather kernel (csrc/attn_gather_fwd.hip: bias on the matrix cores,
+    table taps gathered from an LDS window) instead of the region kernel?  bf16 operands, S <= 224 (a window column holds a
+    key's taps for every BEV row of a column); BEVR_GATHER=0 turns it off (A/B timing)."""
+    return precision == _lib.PREC_BF16 and S <= 224 and os.environ.get("BEVR_GATHER", "1") != "0"
 
 
 class _AttnCore(torch.autograd.Function):
@@ -464,7 +465,7 @@ class _AttnCore(torch.autograd.Function):
             elif ctx.drop:
                 _lib.check(L.bevr_attn_fwd_dropout(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Vt), _ptr(key_ws), _ptr(pair), _ptr(O),
                                                    _ptr(LSE), ctx.drop[0], ctx.drop[1], _stream()), "bevr_attn_fwd_dropout")
-            elif gather_supported(g.precision):
+            elif gather_supported(g.precision, g.S):
                 if pair_pk is None:
                     pair_pk = pair.to(torch.bfloat16)       # (h, Wp, Hp, 2) 16-bit: one dword per (column, row) entry
                     tmax = Ttc.abs().amax(dim=(1, 2))       # Tt is the table in log2 units already

@@ -45,12 +45,13 @@ def calls(L, d, p=P, q=P):
         "tap_fwd": lambda: L.bevr_attn_tap_fwd(r, p, P, P, P, q, P, None),
         "tap_bwd_q": lambda: L.bevr_attn_tap_bwd_q(r, p, P, P, P, q, P, None),
         "tap_bwd_k": lambda: L.bevr_attn_tap_bwd_k(r, p, P, P, P, q, P, P, P, None),
+        "gather_fwd": lambda: L.bevr_attn_gather_fwd(r, p, P, P, P, P, P, q, P, P, None),
     }
 
 
 NAMES = list(calls(None, desc()).keys()) if False else [
     "key_prep", "fwd", "bwd_q", "bwd_k", "fwd_dropout", "bwd_q_dropout", "bwd_k_dropout", "cell_fwd", "cell_bwd_q",
-    "cell_bwd_k", "tap_prep", "tap_fwd", "tap_bwd_q", "tap_bwd_k"]
+    "cell_bwd_k", "tap_prep", "tap_fwd", "tap_bwd_q", "tap_bwd_k", "gather_fwd"]
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -77,6 +78,10 @@ def test_contract_limits_of_the_specialised_entry_points(L):
     # the cell kernels run one wave per 32-row block of a BEV column: Sp <= 512
     big = ops.AttnGeom(n_prob=1, q_div=1, heads=1, groups=1, S=530, N=64, Wt=2 * 530 - 1, precision=_lib.PREC_BF16).desc()
     assert calls(L, big)["cell_fwd"]() == E_SHAPE
+    # the gather forward: bf16 operands; a window column holds a key's taps for every BEV row of a column: S <= 224
+    assert calls(L, desc(precision=_lib.PREC_F32))["gather_fwd"]() == E_PRECISION
+    tall = ops.AttnGeom(n_prob=1, q_div=1, heads=1, groups=1, S=230, N=64, Wt=2 * 230 - 1, precision=_lib.PREC_BF16).desc()
+    assert calls(L, tall)["gather_fwd"]() == E_SHAPE
     # a dropout threshold is a 16-bit number
     r = C.byref(desc())
     assert L.bevr_attn_fwd_dropout(r, P, P, P, P, P, P, P, 65536, 1, None) == E_SHAPE

@@ -12,8 +12,8 @@ L.bevr_debug_prof_gather(buf, 1)
 exec(open(os.path.join(ROOT, "tools", "prof_sca.py")).read())
 torch.cuda.synchronize()
 L.bevr_debug_prof_gather(buf, 0)
-pn = ["stage_keys", "advance+ct", "own-fill stores (wait)", "fill total", "barrier wait", "n", "issue fill loads", ""]
-cn = ["barrier wait", "compute", "own-fill store (wait)", "fill_rest", "loop total", "n", "", ""]
+pn = ["", "advance+stage", "", "wait fills+kv", "barrier wait", "n", "issue fills", ""]
+cn = ["barrier wait", "compute", "wait fills", "", "loop total", "n", "", ""]
 v = list(buf[0:8]); n = max(v[5], 1)
 print("producer", {k: round(x / n, 1) for k, x in zip(pn, v) if k and k != "n"}, "n", v[5])
 for w, o in ((0, 8), (3, 16)):

@@ -14,7 +14,8 @@ NAMES = {"attn_fwd_kernel": "bevr_attn_fwd", "attn_bwd_q_kernel": "bevr_attn_bwd
          "attn_bwd_k_gather_kernel": "bevr_attn_bwd_k", "sample_fwd_kernel": "bevr_sample_fwd", "sample_bwd_kernel": "bevr_sample_bwd", "sample_bwd_patch_kernel": "bevr_sample_bwd", "kv_project_kernel": "bevr_kv_project",
          "attn_cell_fwd_kernel": "bevr_attn_cell_fwd", "attn_cell_bwd_q_kernel": "bevr_attn_cell_bwd_q",
          "attn_cell_bwd_k_kernel": "bevr_attn_cell_bwd_k", "attn_tap_fwd_kernel": "bevr_attn_tap_fwd",
-         "attn_tap_bwd_q_kernel": "bevr_attn_tap_bwd_q", "attn_tap_bwd_k_kernel": "bevr_attn_tap_bwd_k"}
+         "attn_tap_bwd_q_kernel": "bevr_attn_tap_bwd_q", "attn_tap_bwd_k_kernel": "bevr_attn_tap_bwd_k",
+         "attn_gather_fwd_kernel": "bevr_attn_gather_fwd"}
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(int))
 for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):

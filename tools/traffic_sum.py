@@ -31,7 +31,9 @@ for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             # one entry point = one launch: the gather kernel rides with the window kernel, a cell kernel's slow pass
             # (template argument true) with its fast pass
             # (the tap kernels' second launches -- exact pass <.., true>, slow pass <.., true> -- ride with the first)
-            if "gather" not in m.group(1) and not re.search(r"attn_(cell|tap)_\w+_kernel<[\d, ]*true", r["Kernel_Name"]):
+            # (the gather forward's exact pass <.., true, ..> rides with its first launch)
+            if m.group(1) != "attn_bwd_k_gather_kernel" and not re.search(r"attn_(cell|tap)_\w+_kernel<[\d, ]*true", r["Kernel_Name"]) \
+                    and not re.search(r"attn_gather_fwd_kernel<\d+, \d+, true", r["Kernel_Name"]):
                 launches[k][counter] += 1
 out = {"_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `" + cmd + "`; bytes summed over the "
                    "launches of the timed AND warm-up step, averaged per launch (bwd_k = window + gather kernels of one call). "

@@ -39,7 +39,8 @@ class BEVRender(nn.Module):
             strides=config["DAT_STRIDES"], n_groups=config["DAT_NUM_GROUPS"], kernel_size=config["DAT_K_SIZES"],
             drop_rate=config["DAT_DROP_RATE"], attn_drop_rate=config["DAT_ATTN_DROP_RATE"],
             drop_path_rate=config["DAT_DROP_PATH_RATE"], backbone_arch=config["DAT_BACKBONE_TYPE"],
-            data_type=config["DATA_TYPE"], logger=logger, precision=config.get("PRECISION"))
+            data_type=config["DATA_TYPE"], logger=logger, precision=config.get("PRECISION"),
+            stage_dtype=config.get("STAGE_DTYPE"))
         self.decoder = BEVImageRenderDecoder(bev_spatial_dim=config["DAT_BEV_SHAPE"][-1],
                                              model_dim=config["DAT_EMBED_DIMS"][-1],
                                              hid_dim=config["DECODER_HID_DIM"], logger=logger)

@@ -135,9 +135,16 @@ class BEVEncoder(nn.Module):
                  bev_depth_dim=5, z_shift=-1.0, depths=(2,) * 7, n_heads=(2, 4, 8, 16, 8, 4, 2),
                  strides=(8, 4, 2, 1, 2, 4, 8), n_groups=(1, 2, 4, 8, 4, 2, 1), kernel_size=(9, 7, 5, 3, 5, 7, 9),
                  drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.2, backbone_arch="ResNet18",
-                 data_type=torch.float32, logger=None, precision=None):
+                 data_type=torch.float32, logger=None, precision=None, stage_dtype=None):
         super().__init__()
         self.logger = logger
+        # staging dtype of the camera images and of the backbone features they become.  None: whatever
+        # the caller passes (the reference's behaviour); torch.bfloat16 / "bf16": the images are cast once, channels-last,
+        # the backbone runs under autocast, and its features reach the sampler in bf16 -- the form the 16-bit attention
+        # modes read without a float copy (`bevr_sample_*_bf16`, `bevr_kv_project`)
+        if isinstance(stage_dtype, str):
+            stage_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": None}[stage_dtype]
+        self.stage_dtype = stage_dtype
         if backbone_arch == "ResNet18":
             self.img_backbone = ResNet18_wo_fpn(bev_dim=bev_feat_shapes[0], logger=logger)
         elif backbone_arch == "PatchProjection":
@@ -163,7 +170,16 @@ class BEVEncoder(nn.Module):
             img_tensor = img_tensor.flatten(0, 1)                      # views into the batch
         # channels-last staging: MIOpen's NHWC convolutions, and features that arrive in the layout
         # the sampling kernel reads ((B*V, Hf, Wf, C) rows) -- ops.sample_features then takes them without a copy
-        return self.img_backbone(img_tensor.contiguous(memory_format=torch.channels_last))
+        return self._staged_backbone(img_tensor)
+
+    def _staged_backbone(self, x):
+        """Backbone on channels-last images; with `stage_dtype` set, on images cast to it under autocast, features in it."""
+        if self.stage_dtype is None:
+            return self.img_backbone(x.contiguous(memory_format=torch.channels_last))
+        x = x.to(self.stage_dtype).contiguous(memory_format=torch.channels_last)
+        with torch.autocast(device_type=x.device.type, dtype=self.stage_dtype):
+            feat = self.img_backbone(x)
+        return feat.to(self.stage_dtype)
 
     def history_features(self, img_tensor):
         """(B, T', V, 3, H, W) -> list of T' feature tensors (B*V, C, Hf, Wf), all frames through the backbone as ONE
@@ -172,7 +188,7 @@ class BEVEncoder(nn.Module):
         frames are independent and one launch set serves them all."""
         B, Tn, V = img_tensor.shape[:3]
         x = img_tensor.permute(1, 0, 2, 3, 4, 5).reshape(Tn * B * V, *img_tensor.shape[3:])   # frame-major
-        feat = self.img_backbone(x.contiguous(memory_format=torch.channels_last))
+        feat = self._staged_backbone(x)
         return list(feat.reshape(Tn, B * V, *feat.shape[1:]).unbind(0))
 
     def forward(self, bev_query, img_tensor, prev_bev, vehicle_pose, vehicle_type_idx, wandb_log_dict,

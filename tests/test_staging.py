@@ -1,0 +1,76 @@
+"""bf16 staging of the camera images and backbone features (reference: model/encoder.py:98-110, where
+the images go to the backbone in whatever dtype the config says).  `BEVEncoder(stage_dtype="bf16")` casts the images once,
+channels-last, runs the backbone under autocast and hands the features over in bf16 -- the form the 16-bit attention
+modes read without a float copy."""
+import importlib.util
+import logging
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("mgf", os.path.join(HERE, "golden", "make_golden_full.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _encoders(stage):
+    from bevrender_amd.model.bevrender import BEVRender
+    g = _gen()
+    cfg = g.full_config()
+    cfg["PRECISION"] = "bf16"
+    cfg["STAGE_DTYPE"] = stage
+    for k in ("DAT_DROP_PATH_RATE", "DAT_DROP_RATE", "DAT_ATTN_DROP_RATE"):     # forward() always runs the current frame in
+        cfg[k] = 0.0                                                            # train mode: no random draws to compare
+    torch.manual_seed(11)
+    return BEVRender(cfg, logging.getLogger("t"), "train"), g
+
+
+def test_bf16_staging_of_images_and_features_cpu():
+    """The staging step alone (the backbone is plain PyTorch: runs on the CPU): dtype, layout, closeness to the f32 features,
+    and the history frames as one batch."""
+    m16, g = _encoders("bf16")
+    m32, _ = _encoders(None)
+    m32.load_state_dict(m16.state_dict())
+    m16.eval(), m32.eval()
+    img, _, _ = g.full_inputs()                      # (B, T, V, 3, H, W)
+    cur = img[:, -1]
+    with torch.no_grad():
+        f16 = m16.encoder.backbone_features(cur)
+        f32 = m32.encoder.backbone_features(cur)
+        h16 = m16.encoder.history_features(img[:, :-1])
+    assert m16.encoder.stage_dtype is torch.bfloat16 and m32.encoder.stage_dtype is None
+    assert f16.dtype is torch.bfloat16 and f32.dtype is torch.float32 and f16.shape == f32.shape
+    assert f16.is_contiguous(memory_format=torch.channels_last)
+    err = (f16.float() - f32).abs().max().item() / f32.abs().max().item()
+    assert err < 5e-2, err
+    assert all(h.dtype is torch.bfloat16 and h.shape == f16.shape for h in h16)
+
+
+@pytest.mark.gpu
+def test_bf16_staging_full_model_gpu():
+    """Whole drop-in model with bf16 staging against the same weights with the config's (float) staging, bf16 kernels on
+    both sides: the render output moves by bf16 rounding of the features only, and the backward is finite."""
+    m16, g = _encoders("bf16")
+    m32, _ = _encoders(None)
+    m32.load_state_dict(m16.state_dict())
+    m16, m32 = m16.cuda(), m32.cuda()
+    img, pose, vtype = g.full_inputs()
+    out16, _ = m16(img.cuda(), pose.cuda(), vtype.cuda(), {}, False)
+    with torch.no_grad():
+        out32, _ = m32(img.cuda(), pose.cuda(), vtype.cuda(), {}, False)
+    # an untrained render CNN amplifies the features' bf16 rounding (6 % of their largest value): compare in the 2-norm
+    a, b = out16.float().flatten(), out32.float().flatten()
+    err = ((a - b).norm() / b.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+    assert err < 0.25 and cos > 0.97, (err, cos)
+    out16.float().sum().backward()
+    torch.cuda.synchronize()
+    gq = m16.bev_embedding.weight.grad
+    assert gq is not None and torch.isfinite(gq).all() and gq.abs().sum() > 0

@@ -15,7 +15,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 rows = sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.self_device_time_total)
 tot = sum(e.self_device_time_total for e in rows if "attn_" not in e.key and not e.key.startswith("_") and e.self_device_time_total > 0)
 print(f"non-attention device time: {tot / 1e3:.2f} ms")
-for e in rows[:70]:
-    if "attn_" in e.key or e.self_device_time_total <= 0 or e.key.startswith("void ") or e.key.startswith("Cijk") or e.key.startswith("_"):
+for e in rows[:90]:
+    if "attn_" in e.key or e.self_device_time_total <= 0 or e.key.startswith("_"):
         continue
     print(f"{e.self_device_time_total / 1e3:8.3f} ms {e.count:4d}  {e.key[:28]:28s} {str(e.input_shapes)[:120]}")

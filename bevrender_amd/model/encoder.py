@@ -139,9 +139,9 @@ class BEVEncoder(nn.Module):
         super().__init__()
         self.logger = logger
         # staging dtype of the camera images and of the backbone features they become.  None: whatever
-        # the caller passes (the reference's behaviour); torch.bfloat16 / "bf16": the images are cast once, channels-last,
-        # the backbone runs under autocast, and its features reach the sampler in bf16 -- the form the 16-bit attention
-        # modes read without a float copy (`bevr_sample_*_bf16`, `bevr_kv_project`)
+        # the caller passes (the reference's behaviour); torch.bfloat16 / "bf16": the images are staged once, channels-last,
+        # in bf16, and the backbone's features reach the sampler in bf16 -- the form the 16-bit attention modes read
+        # without a float copy (`bevr_sample_*_bf16`, `bevr_kv_project`)
         if isinstance(stage_dtype, str):
             stage_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": None}[stage_dtype]
         self.stage_dtype = stage_dtype
@@ -173,12 +173,14 @@ class BEVEncoder(nn.Module):
         return self._staged_backbone(img_tensor)
 
     def _staged_backbone(self, x):
-        """Backbone on channels-last images; with `stage_dtype` set, on images cast to it under autocast, features in it."""
+        """Backbone on channels-last images.  With `stage_dtype` set the images are STAGED in it (what a loader would hand
+        over: half the bytes of the input side) and widened to the backbone's own dtype at its door -- the backbone's
+        arithmetic is the config's, not autocast -- and the features leave in `stage_dtype`."""
         if self.stage_dtype is None:
             return self.img_backbone(x.contiguous(memory_format=torch.channels_last))
         x = x.to(self.stage_dtype).contiguous(memory_format=torch.channels_last)
-        with torch.autocast(device_type=x.device.type, dtype=self.stage_dtype):
-            feat = self.img_backbone(x)
+        p = next(self.img_backbone.parameters(), None)
+        feat = self.img_backbone(x if p is None else x.to(p.dtype))
         return feat.to(self.stage_dtype)
 
     def history_features(self, img_tensor):

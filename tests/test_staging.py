@@ -1,7 +1,7 @@
 """bf16 staging of the camera images and backbone features (reference: model/encoder.py:98-110, where
-the images go to the backbone in whatever dtype the config says).  `BEVEncoder(stage_dtype="bf16")` casts the images once,
-channels-last, runs the backbone under autocast and hands the features over in bf16 -- the form the 16-bit attention
-modes read without a float copy."""
+the images go to the backbone in whatever dtype the config says).  `BEVEncoder(stage_dtype="bf16")` stages the images once,
+channels-last, in bf16 and hands the backbone's features over in bf16 -- the form the 16-bit attention modes read without
+a float copy (the map's gradient with bf16 maps: tests/test_gpu_ops.py::test_sample_features_reads_bf16_features_as_they_are)."""
 import importlib.util
 import logging
 import os
@@ -49,28 +49,25 @@ def test_bf16_staging_of_images_and_features_cpu():
     assert f16.dtype is torch.bfloat16 and f32.dtype is torch.float32 and f16.shape == f32.shape
     assert f16.is_contiguous(memory_format=torch.channels_last)
     err = (f16.float() - f32).abs().max().item() / f32.abs().max().item()
-    assert err < 5e-2, err
+    assert err < 3e-2, err
     assert all(h.dtype is torch.bfloat16 and h.shape == f16.shape for h in h16)
 
 
 @pytest.mark.gpu
 def test_bf16_staging_full_model_gpu():
-    """Whole drop-in model with bf16 staging against the same weights with the config's (float) staging, bf16 kernels on
-    both sides: the render output moves by bf16 rounding of the features only, and the backward is finite."""
+    """Whole drop-in model, forward, with bf16 staging against the same weights with the config's (float) staging, bf16
+    kernels on both sides: the render output moves by the bf16 rounding of images and features only."""
     m16, g = _encoders("bf16")
     m32, _ = _encoders(None)
     m32.load_state_dict(m16.state_dict())
     m16, m32 = m16.cuda(), m32.cuda()
     img, pose, vtype = g.full_inputs()
-    out16, _ = m16(img.cuda(), pose.cuda(), vtype.cuda(), {}, False)
     with torch.no_grad():
+        out16, _ = m16(img.cuda(), pose.cuda(), vtype.cuda(), {}, False)
         out32, _ = m32(img.cuda(), pose.cuda(), vtype.cuda(), {}, False)
-    # an untrained render CNN amplifies the features' bf16 rounding (6 % of their largest value): compare in the 2-norm
+    torch.cuda.synchronize()
+    # an untrained render CNN amplifies the features' bf16 rounding: compare in the 2-norm
     a, b = out16.float().flatten(), out32.float().flatten()
     err = ((a - b).norm() / b.norm()).item()
     cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
-    assert err < 0.25 and cos > 0.97, (err, cos)
-    out16.float().sum().backward()
-    torch.cuda.synchronize()
-    gq = m16.bev_embedding.weight.grad
-    assert gq is not None and torch.isfinite(gq).all() and gq.abs().sum() > 0
+    assert torch.isfinite(a).all() and err < 0.25 and cos > 0.97, (err, cos)

@@ -26,9 +26,11 @@
 // ANY key set is handled: a tile whose box does not fit the window (more than WIN_COLS columns or PITCH rows) is emitted
 // in groups of 14 keys with one two-column STRIP of the table per key, the other keys masked.
 //
-// Softmax reference: the maximum of the row's first tile, raised (with a rescale) only when a later logit exceeds it
-// by more than 2^RAISE -- weights up to 2^RAISE are exact in bf16 and in the f32 sums.  The exact row maximum is
-// tracked beside it for LSE plane 1.
+// Softmax reference: STATIC.  The first pass works against the caller's mref[q] (an upper bound of the row's logits minus
+// a headroom, bevrender_amd/ops.py): no running maximum, rescale or mass test in the loop.  A row whose weights all
+// underflowed against it flags its column and the EXACT instantiation -- the only one with an online maximum (the
+// maximum of the row's first tile, raised with a rescale when a later logit exceeds it) -- recomputes that column.
+// The row's largest weight is tracked beside the sums for LSE plane 1.
 #include "attn_tap.h"
 
 #ifdef BEVR_GPROF

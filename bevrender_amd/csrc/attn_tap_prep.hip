@@ -52,6 +52,10 @@ __global__ __launch_bounds__(256) void attn_tap_prep_kernel(bevr_attn_desc d, co
   // NaN positions sample nothing (every hat() of a NaN is 0 through fmaxf)
   r.ys = live ? key_y[idx] : TAP_YS_DEAD;
   r.xs = live ? key_x[idx] : 0.f;
+  // the tap contract (attn_tap.h): a live key samples inside feature rows 0..3 x columns 0..2.  A key beyond them would
+  // silently lose the taps the 12-pixel grid does not hold; the bounds-checking build traps (NaN positions sample nothing
+  // and compare false)
+  BEVR_ASSERT(!(live && (r.ys >= (float)(TAP_R - 1) || r.xs >= (float)(TAP_C - 1))));
   rec_out[idx] = r;
   if ((lane & 31) == 0) {
     StepBox sb;

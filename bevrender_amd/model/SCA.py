@@ -100,7 +100,7 @@ class SpatialCrossAttn(nn.Module):
             img_feat = img_feat.reshape(B, self.num_views, *img_feat.shape[1:])
         return self.spatial_deform_attn(x=img_feat, query=query, reference_points=ref,
                                         wandb_log_dict=wandb_log_dict, return_wandb_log=return_wandb_log,
-                                        key_order=order, cell_split=split)
+                                        key_order=order, cell_split=split, split_is_pinned=True)
 
     def _code(self, t: torch.Tensor) -> int:
         # One rig per model in the reference (VEHICLE_TYPE_CODE); avoid its per-call .item() sync when possible.

@@ -132,13 +132,19 @@ class SCADeformableAttention(nn.Module):
         return (ymax < ops.TAP_R - 1 - 1e-3 or Hi <= ops.TAP_R) and (xmax < ops.TAP_C - 1 - 1e-3 or Wi <= ops.TAP_C)
 
     def forward(self, x, query, reference_points, wandb_log_dict, return_wandb_log=True, key_order=None,
-                cell_split=None):
+                cell_split=None, split_is_pinned=False):
         """x (B, V, C, Hi, Wi); query (B, C, S, S); reference_points (B, V, S/2, S*D, 2) in (x, y).
         key_order (V, N) long, optional: a per-view permutation of the keys (SpatialCrossAttn passes the static
         k-d order of the camera projections); it changes no result, only the memory locality of the bias.
-        cell_split, optional: in that order the keys [cell_split, N) of every view are the ones the projector pinned to
-        pixel (0, 0); they are sorted by rpe-table cell here, per call (their learned offsets decide the cell), and
-        attended through the cell kernels (ops.attention_core).  Changes no result either."""
+        cell_split, optional: the keys [cell_split, N) of every view (in that order) form a second key segment: they are
+        sorted by rpe-table cell here, per call (their learned offsets decide the cell), and attended through the cell
+        kernels (ops.attention_core), which handle ANY key set: the split changes no result.
+        split_is_pinned=True is the caller's PROMISE that every key of [cell_split, N) has its reference exactly at
+        (-1, -1) -- the pillar points the projector pins to pixel (0, 0); SpatialCrossAttn builds its split that way and
+        passes True.  Only then, in the bf16 operand mode and with the offsets inside the tanh range (_pinned_keys_tap),
+        does the segment run on the TAP kernels, which never form K and V and are exact only for keys that sample inside
+        the top-left 4 x 3 feature pixels (csrc/attn_tap.h; the DEBUG build traps on a key outside them).  Without the
+        promise a caller's own reference_points / split stay on the cell kernels."""
         B, V, C, Hi, Wi = x.shape
         S = query.shape[-1]
         if V != self.n_views:
@@ -172,7 +178,8 @@ class SCADeformableAttention(nn.Module):
             feat = (xf if xf.dtype == torch.bfloat16 else xf.float()).permute(0, 2, 3, 1).contiguous()
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
                                    precision=self.precision, kv_source=(feat, Wkv, bkv), cell_split=cell_split,
-                                   tap_source=cell_split is not None and self._pinned_keys_tap(S, Hi, Wi), attn_drop=drop)
+                                   tap_source=bool(split_is_pinned) and cell_split is not None and self._pinned_keys_tap(S, Hi, Wi),
+                                   attn_drop=drop)
         else:
             xs = ops.sample_features(xf, pos, g)                                     # (B*V, N, C)
             kv = F.linear(xs, Wkv, bkv)

@@ -1,6 +1,6 @@
 """Data parallelism for the BEV-lift path: one process per GPU, batch sharded across ranks, gradients
-averaged with one bucketed all-reduce overlapped with backward (RCCL over xGMI under the "nccl" backend;
-"gloo" on CPU for tests).
+averaged by bucketed all-reduces that start while the backward is still running (RCCL over xGMI under the
+"nccl" backend; "gloo" on CPU for tests).
 
 Counterpart of the reference's DDP use (train.py:29-32 init_process_group, :128-141 SyncBatchNorm + DDP wrap
 with find_unused_parameters=True, :668 DistributedSampler).  Differences by design:
@@ -8,8 +8,13 @@ with find_unused_parameters=True, :668 DistributedSampler).  Differences by desi
     SCA offset heads of absent views) are frozen up front, so the reducer needs no unused-parameter search
     (a device->host sync per step in the reference);
   * every op on the hot path is per-sample independent (LayerNorm only, no BatchNorm inside TSA/SCA), so
-    there is no data-path collective: ~2-3 M parameters = 8-11 MB of fp32 gradients = ONE 25 MB bucket,
-    latency-bound on a ring over xGMI and hidden behind the backward of the attention kernels.
+    there is no data-path collective: ~2-3 M parameters = 8-11 MB of fp32 gradients.  PyTorch's default 25 MB bucket
+    would hold all of them and fire only when the LAST gradient (the backbone's first convolution) is ready -- an
+    all-reduce exposed after the backward (round 4).  The bucket size is therefore derived from the gradient volume
+    (N_BUCKETS buckets): the render decoder's and the last encoder layer's gradients are reduced while the attention
+    kernels of the first layer still run.  DDP rebuilds its buckets in gradient-ready order after the first step
+    (find_unused_parameters=False): the FIRST step still uses one bucket, every later one N_BUCKETS.
+    Unmeasured on hardware: no multi-GPU node was available to any round so far.
 """
 from __future__ import annotations
 
@@ -52,8 +57,23 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     return rank, world, local_rank
 
 
-def wrap_data_parallel(model: nn.Module, local_rank: int | None = None, bucket_cap_mb: int = 25) -> nn.Module:
-    """DistributedDataParallel with one flat bucket and no unused-parameter search; identity when world == 1.
+N_BUCKETS = 4     # gradient buckets per step: the last ones' all-reduce runs under the backward of the earlier layers
+
+
+def gradient_bytes(model: nn.Module) -> int:
+    return sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad)
+
+
+def bucket_count(ddp: nn.Module) -> int:
+    """Gradient buckets the reducer of a DistributedDataParallel module uses right now (1 before the first backward:
+    the buckets are rebuilt in gradient-ready order after it)."""
+    return len(ddp.reducer._get_zeros_like_grad_buckets())
+
+
+def wrap_data_parallel(model: nn.Module, local_rank: int | None = None, bucket_cap_mb: float | None = None) -> nn.Module:
+    """DistributedDataParallel without an unused-parameter search and with N_BUCKETS gradient buckets (bucket_cap_mb
+    None: gradient volume / N_BUCKETS, so that a bucket's all-reduce overlaps the rest of the backward; the reference
+    takes PyTorch's 25 MB default, train.py:133-135); identity when world == 1.
 
     BatchNorm layers (image backbone, render decoder -- none on the hot path) keep the reference's semantics
     (train.py:128-141 converts to SyncBatchNorm before wrapping): on GPU process groups they are converted to
@@ -64,6 +84,8 @@ def wrap_data_parallel(model: nn.Module, local_rank: int | None = None, bucket_c
     on_gpu = next(model.parameters()).is_cuda
     has_bn = any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in model.modules())
     sync_bn = has_bn and on_gpu and dist.get_backend() == "nccl"
+    if bucket_cap_mb is None:
+        bucket_cap_mb = max(gradient_bytes(model) / N_BUCKETS, 1024) / float(1 << 20)
     if sync_bn:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     return nn.parallel.DistributedDataParallel(

@@ -43,7 +43,8 @@ extern "C" {
 /* 3: bevr_attn_fwd writes TWO LSE planes (round 2 changed that under version 2: a version-2 caller's [n_prob][heads][Mp]
  *    buffer is too small), the key workspace carries group boxes, bevr_attn_bwd_q takes grad_scale; new: bevr_attn_cell_*,
  *    problem strides of bevr_pack_kv / bevr_unpack_dkv, BEVR_PREC_F16, grad_scale[8] for every backward entry point. */
-/* 4: new entry points bevr_attn_tap_* (the projector-pinned keys without K / V) and bevr_attn_*_dropout; nothing else
+/* 4: new entry points bevr_attn_tap_* (the projector-pinned keys without K / V), bevr_attn_gather_fwd (the forward over
+ *    scattered keys with the bias on the matrix cores) and bevr_attn_*_dropout; nothing else
  *    changed. */
 #define BEVR_ABI_VERSION 4
 
@@ -245,8 +246,12 @@ int bevr_attn_cell_bwd_k(const bevr_attn_desc* d, const void* Q, const void* Qt,
  *       offset c = Gb[q] - mref[q] (hi = E(c), lo = E(c - hi): the matrix product adds them against ones on the key side);
  *       slot 14 = -1e30 (E = bf16) / -60000 (fp16): the logit of a masked key; slot 15 zero
  *   mref [n_prob][heads][Mp] float IN/OUT: the softmax reference of each row, AS THE KERNEL SEES IT (Gb - (hi + lo)).  In:
- *       an upper bound of the row's logits minus a headroom of <= 100 (no weight can then overflow; bevrender_amd/ops.py
- *       uses max(0, max_t G) + Gb + max(0, max table) - 64).  Out: the reference R is relative to -- unchanged unless
+ *       an upper bound of the row's logits minus a HEADROOM (bevrender_amd/ops.py uses max(0, max_t G) + Gb +
+ *       max(0, max table) - 64).  The weights 2^(S - mref) <= 2^headroom are rounded to the operand type E before the R
+ *       product, so the headroom is bounded per precision: BEVR_PREC_BF16 <= 100 (8 exponent bits), BEVR_PREC_F16 <= 8
+ *       (5 exponent bits: 2^15.9 is fp16's largest value; the row sum over up to 2^17 keys is taken in f32.  A larger fp16
+ *       headroom gives inf / NaN in R -- the kernel cannot see the headroom, the limit is the caller's to keep;
+ *       tools/tap_check.py runs fp16 at 8, bevrender_amd/ops.py keeps fp16 calls off these entry points).  Out: the reference R is relative to -- unchanged unless
  *       every weight of the row underflowed against the bound (looser than ~190 binades), in which case the column is
  *       recomputed with an online maximum and its rows' mref are replaced.
  *   R   [n_prob][heads][Mp][16] float (written; rows 12, 13 equal row 15)   flags [n_prob*heads][S] int32, ZEROED by the
@@ -271,13 +276,19 @@ int bevr_attn_tap_bwd_q(const bevr_attn_desc* d, const void* G, const void* H, c
  *   d/d key_a, d/d key_b through the bias (bilinear derivative of the table), d/d key_y, d/d key_x through the tap
  *   weights -- both paths of it: the logits (G) and the values (sum_q P H / ln2: H carries ln2 dO . Vpix).  Kinks as F.grid_sample's backward
  *   (floor-based: the derivative of the tap pair the position sits between). */
+/* NOTE the table operand: NOT the pair table of the other entry points but the PLAIN packed table
+ *   table [heads][Wp][Hp + 1] float, table[h][x][y] = log2(e) * rpe_table[h][y - y_off][x - x_off], zero in the padding --
+ *   the transposed, padded table the pair table is built from and the buffer `dtable` mirrors (row pitch Hp + 1).  The
+ *   kernel differences it along both axes in hi + lo 16-bit parts; handing it the (h, Wp, Hp, 2) pair table gives silently
+ *   wrong dkey_a / dkey_b (tests/test_gpu_tap.py::test_tap_bwd_k_through_the_c_abi_as_the_header_describes). */
 int bevr_attn_tap_bwd_k(const bevr_attn_desc* d, const void* G, const void* H, const void* tap_ws,
-                        const float* table_pair, float* dkey_a, float* dkey_b, float* dkey_y, float* dkey_x, void* stream);
+                        const float* table, float* dkey_a, float* dkey_b, float* dkey_y, float* dkey_x, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Gather kernels: the attention of bevr_attn_fwd / _bwd_* for SCATTERED keys with the relative-position bias on the
- * matrix cores (csrc/attn_gather_fwd.hip: a sparse contraction whose table side the lanes gather from an LDS window of
- * the table; any key set is handled).  BEVR_PREC_BF16 only, S <= 224.  Replaces model/SCA_deform_attn.py:331-413 and
+ * Gather kernel: the FORWARD of bevr_attn_fwd for SCATTERED keys with the relative-position bias on the matrix cores
+ * (csrc/attn_gather_fwd.hip: a sparse contraction whose table side the lanes gather from an LDS window of the table;
+ * any key set is handled; there is no gather backward: bevr_attn_bwd_q / _bwd_k or the slab entry point below take the
+ * same operands).  BEVR_PREC_BF16 only, S <= 224.  Replaces model/SCA_deform_attn.py:331-413 and
  * model/TSA_deform_attn.py:245-333 (reference) like the entry points above.
  *   Q, K, key_ws, O, LSE: as bevr_attn_fwd        V [n_prob][heads][Np][32] bf16 rows (not transposed)
  *   table_pk [heads][Wp][Hp] dwords: the pair table in bf16, (T2[y - y_off][x - x_off], T2[y + 1 - y_off][x - x_off]),

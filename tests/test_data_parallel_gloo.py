@@ -51,8 +51,17 @@ def _worker(rank, world, port, state, x, out_q):
     frozen = parallel.freeze_unused_parameters(model)
     assert any("proj_q" in n for n in frozen) and any("ffn_tsa" in n for n in frozen)
     net = parallel.wrap_data_parallel(model)
-    loss = net(parallel.shard_batch(x, rank, world))
+    assert parallel.bucket_count(net) == 1          # before the first backward: one bucket (DDP's initial assignment)
+    xs = parallel.shard_batch(x, rank, world)
+    for _ in range(2):                              # DDP rebuilds its buckets in gradient-ready order after step 1
+        net.zero_grad(set_to_none=True)
+        net(xs).backward()
+    net.zero_grad(set_to_none=True)
+    loss = net(xs)
     loss.backward()
+    # gradient volume / N_BUCKETS per bucket: the all-reduce of the layers that finish first runs under the backward of the
+    # rest (train.py:133-135 of the reference takes the 25 MB default = one bucket after the last gradient)
+    assert parallel.bucket_count(net) >= 2, parallel.bucket_count(net)
     grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.requires_grad}
     if rank == 0:
         out_q.put({k: v.numpy() for k, v in grads.items()})

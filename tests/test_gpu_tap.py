@@ -48,6 +48,21 @@ def test_tap_entry_points_match_their_float64_definition(name):
         assert r[k] < lim_g, (k, r)
 
 
+def test_tap_bwd_k_through_the_c_abi_as_the_header_describes():
+    """include/bevrender_hip.h declared bevr_attn_tap_bwd_k's table operand as `table_pair`; the kernel reads
+    the PLAIN packed table [heads][Wp][Hp + 1].  The header now says so; this test builds the operand from the header's
+    words alone (tap_check.header_table, not ops.pack_table) and holds d(key_a), d(key_b) -- the two outputs that read it --
+    to the float64 definition, and checks that the pair table (what the old declaration asked for) does NOT pass."""
+    import tap_check
+    kw = dict(P=2, h=2, S=24, N=500, Wt=2 * 24 * 3 - 1, seed=7)
+    r = tap_check.check_case("header table", from_header=True, **kw)
+    for k in ("da", "db", "dys", "dxs"):
+        assert r[k] < 3e-2, (k, r)
+    geom, a, b, ys, xs, G, Gb, T = tap_check.make_case(**kw)
+    assert tuple(tap_check.header_table(T, geom).shape) == (geom.heads, geom.Wp, geom.Hp + 1)
+    assert torch.equal(tap_check.header_table(T, geom), ops.pack_table(T.float(), geom).contiguous())
+
+
 def test_tap_forward_recomputes_rows_whose_weights_underflow_the_static_reference():
     """logit scale 200: the upper bound of a row's logits is hundreds of binades above the logits that carry its mass,
     every weight underflows against the static reference, the column is flagged and recomputed with an online maximum.

@@ -55,19 +55,31 @@ def test_bf16_staging_of_images_and_features_cpu():
 
 @pytest.mark.gpu
 def test_bf16_staging_full_model_gpu():
-    """Whole drop-in model, forward, with bf16 staging against the same weights with the config's (float) staging, bf16
-    kernels on both sides: the render output moves by the bf16 rounding of images and features only."""
+    """Whole drop-in model, forward AND backward, with bf16 staging against the same weights with the config's (float)
+    staging, bf16 kernels on both sides: the render output moves by the bf16 rounding of images and features only, and the
+    backward -- bf16 feature maps that carry a gradient through the fused K | V adjoint and the sampler's scatter, the tap /
+    gather / region kernels inside `BEVRender`, the `feat.to(stage_dtype)` adjoint into MIOpen's backbone backward -- gives
+    finite, non-zero gradients at both ends of the model (the backward this test lost in round 4)."""
     m16, g = _encoders("bf16")
     m32, _ = _encoders(None)
     m32.load_state_dict(m16.state_dict())
     m16, m32 = m16.cuda(), m32.cuda()
     img, pose, vtype = g.full_inputs()
+    out16, _ = m16(img.cuda(), pose.cuda(), vtype.cuda(), {}, False)
     with torch.no_grad():
-        out16, _ = m16(img.cuda(), pose.cuda(), vtype.cuda(), {}, False)
         out32, _ = m32(img.cuda(), pose.cuda(), vtype.cuda(), {}, False)
     torch.cuda.synchronize()
     # an untrained render CNN amplifies the features' bf16 rounding: compare in the 2-norm
-    a, b = out16.float().flatten(), out32.float().flatten()
+    a, b = out16.detach().float().flatten(), out32.float().flatten()
     err = ((a - b).norm() / b.norm()).item()
     cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
     assert torch.isfinite(a).all() and err < 0.25 and cos > 0.97, (err, cos)
+    out16.float().sum().backward()
+    torch.cuda.synchronize()
+    gq = m16.bev_embedding.weight.grad
+    assert gq is not None and torch.isfinite(gq).all() and gq.abs().sum() > 0
+    # the far end of the backward: the backbone's first convolution, reached only through the bf16 feature maps' gradient
+    gb = next(p.grad for p in m16.encoder.img_backbone.parameters() if p.requires_grad)
+    assert gb is not None and torch.isfinite(gb).all() and gb.abs().sum() > 0
+    bad = [n for n, p in m16.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+    assert not bad, bad

@@ -1,4 +1,4 @@
-"""attn_gather_fwd phase cycle breakdown with the instrumented build (make -C bevrender_amd/csrc PROF=1 OUTDIR=../lib_prof)."""
+"""attn_gather_fwd phase cycle breakdown with the instrumented build (make -C bevrender_amd/csrc GPROF=1 OUTDIR=../lib_prof; PROF=1 is the region bwd_q's stamps and does not export bevr_debug_prof_gather)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -203,8 +203,17 @@ def relerr(got, want):
     return ((got - want).abs().max() / want.abs().max().clamp_min(1e-30)).item()
 
 
+def header_table(T, geom):
+    """The `table` operand of bevr_attn_tap_bwd_k built from the words of include/bevrender_hip.h alone:
+    table[h][x][y] = log2(e) * rpe_table[h][y - y_off][x - x_off], zero in the padding, shape [heads][Wp][Hp + 1]."""
+    t = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=T.device, dtype=torch.float32)
+    t[:, geom.x_off:geom.x_off + geom.Wt, geom.y_off:geom.y_off + geom.Ht] = (T.float() * ops.LOG2E).transpose(1, 2)
+    return t.contiguous()
+
+
 def check_case(name, **kw):
     headroom = kw.pop("headroom", 64.0)
+    from_header = kw.pop("from_header", False)
     geom, a, b, ys, xs, G, Gb, T = make_case(**kw)
     R, mref, flags, _, _ = run_fwd(geom, a, b, ys, xs, G, Gb, T, headroom)
     torch.cuda.synchronize()
@@ -243,7 +252,7 @@ def check_case(name, **kw):
     leak = dT.double().abs().sum() - dTg.abs().sum()
     print(f"{'':28s} bwd_q: dG {relerr(dGg[..., :12], wdG[..., :12]):.2e}  dGb {relerr(dGg[..., 15], wdG[..., 15]):.2e}  "
           f"dtable {relerr(dTg, wdT):.2e} (outside the table {leak.item():.1e})")
-    Tt = ops.pack_table(T.float(), geom).contiguous()
+    Tt = header_table(T, geom) if from_header else ops.pack_table(T.float(), geom).contiguous()
     da, db, dy, dx = [t.double()[:, :geom.N] for t in run_bwd_k(geom, G, Gc, H, Hc, ws, Tt)]
     print(f"{'':28s} bwd_k: da {relerr(da, wda):.2e}  db {relerr(db, wdb):.2e}  dys {relerr(dy, wdy):.2e}  dxs {relerr(dx, wdx):.2e}")
     out.update(flagged=int(flags.sum()), dG=relerr(dGg[..., :12], wdG[..., :12]), dGb=relerr(dGg[..., 15], wdG[..., 15]),

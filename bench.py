@@ -116,6 +116,7 @@ class LiftBlock(nn.Module):
 # the tap kernels run FEWER matrix flops than these counts (contraction 12 taps instead of 32 channels): the counts
 # are the algorithm's, not the instruction stream's.
 N_MATMUL = {"bevr_attn_fwd": 2, "bevr_attn_bwd_q": 3, "bevr_attn_bwd_k": 4, "bevr_attn_gather_fwd": 2,
+            "bevr_attn_slab_bwd_q": 3,
             "bevr_attn_cell_fwd": 2, "bevr_attn_cell_bwd_q": 3, "bevr_attn_cell_bwd_k": 4,
             "bevr_attn_tap_fwd": 2, "bevr_attn_tap_bwd_q": 3, "bevr_attn_tap_bwd_k": 4}
 ALG_MATMUL = {k: (2.0 if k.endswith("fwd") else 2.5) for k in N_MATMUL}

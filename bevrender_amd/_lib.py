@@ -20,13 +20,13 @@ LIB_PATH = os.environ.get("BEVRENDER_LIB") or os.path.join(_HERE, "lib", "libbev
 CSRC = os.path.join(_HERE, "csrc")
 
 PREC_F32, PREC_BF16, PREC_F16, PREC_BF16X3 = 0, 1, 2, 3
-ABI_VERSION = 4   # BEVR_ABI_VERSION of include/bevrender_hip.h this binding was written against
+ABI_VERSION = 5   # BEVR_ABI_VERSION of include/bevrender_hip.h this binding was written against
 
 # every symbol include/bevrender_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "bevr_abi_version", "bevr_strerror", "bevr_attn_table_dims", "bevr_attn_key_ws_bytes", "bevr_attn_key_prep",
     "bevr_attn_fwd", "bevr_attn_bwd_q",
-    "bevr_attn_bwd_k", "bevr_attn_fwd_dropout", "bevr_attn_bwd_q_dropout", "bevr_attn_bwd_k_dropout", "bevr_attn_cell_fwd", "bevr_attn_cell_bwd_q", "bevr_attn_cell_bwd_k", "bevr_attn_tap_ws_bytes", "bevr_attn_tap_prep", "bevr_attn_tap_fwd", "bevr_attn_tap_bwd_q", "bevr_attn_tap_bwd_k", "bevr_attn_gather_fwd", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_sample_fwd_bf16", "bevr_sample_bwd_bf16", "bevr_project_bev_grid", "bevr_project_bev_grid_masked", "bevr_corr_fwd",
+    "bevr_attn_bwd_k", "bevr_attn_fwd_dropout", "bevr_attn_bwd_q_dropout", "bevr_attn_bwd_k_dropout", "bevr_attn_cell_fwd", "bevr_attn_cell_bwd_q", "bevr_attn_cell_bwd_k", "bevr_attn_tap_ws_bytes", "bevr_attn_tap_prep", "bevr_attn_tap_fwd", "bevr_attn_tap_bwd_q", "bevr_attn_tap_bwd_k", "bevr_attn_gather_fwd", "bevr_attn_slab_ws_bytes", "bevr_attn_slab_prep", "bevr_attn_slab_bwd_q", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_sample_fwd_bf16", "bevr_sample_bwd_bf16", "bevr_project_bev_grid", "bevr_project_bev_grid_masked", "bevr_corr_fwd",
     "bevr_corr_bwd", "bevr_recall_rank", "bevr_dwconv_fwd", "bevr_dwconv_bwd_w", "bevr_affine_warp_fwd", "bevr_affine_warp_bwd",
     "bevr_offset_head_fwd", "bevr_offset_head_bwd", "bevr_key_positions_fwd", "bevr_key_positions_bwd", "bevr_kv_project", "bevr_layernorm_fwd", "bevr_layernorm_bwd", "bevr_pack_kv", "bevr_unpack_dkv",
 ]
@@ -96,6 +96,9 @@ def lib() -> C.CDLL:
         L.bevr_attn_tap_bwd_q.argtypes = [dp, vp, vp, vp, fp, fp, fp, vp]
         L.bevr_attn_tap_bwd_k.argtypes = [dp, vp, vp, vp, fp, fp, fp, fp, fp, vp]
         L.bevr_attn_gather_fwd.argtypes = [dp, vp, vp, vp, vp, vp, fp, fp, fp, vp, vp]
+        L.bevr_attn_slab_ws_bytes.argtypes = [dp]
+        L.bevr_attn_slab_prep.argtypes = [dp, fp, fp, vp, vp, vp]
+        L.bevr_attn_slab_bwd_q.argtypes = [dp, vp, vp, vp, vp, fp, vp, fp, fp, fp, fp, fp, vp]
         L.bevr_sample_fwd.argtypes = [fp, fp, fp] + [ip] * 5 + [vp]
         L.bevr_sample_bwd.argtypes = [fp] * 5 + [ip] * 5 + [vp]
         L.bevr_sample_fwd_bf16.argtypes = [vp, fp, fp] + [ip] * 5 + [vp]
@@ -120,7 +123,7 @@ def lib() -> C.CDLL:
         L.bevr_unpack_dkv.argtypes = [fp] * 4 + [C.c_longlong, C.c_longlong] + [ip] * 5 + [vp]
         for name in SYMBOLS:
             fn = getattr(L, name)
-            if name in ("bevr_attn_key_ws_bytes", "bevr_attn_tap_ws_bytes"):
+            if name in ("bevr_attn_key_ws_bytes", "bevr_attn_tap_ws_bytes", "bevr_attn_slab_ws_bytes"):
                 fn.restype = C.c_size_t
             elif name not in ("bevr_strerror",):
                 fn.restype = C.c_int

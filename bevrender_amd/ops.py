@@ -379,6 +379,14 @@ def gather_supported(precision, S) -> bool:
     return precision == _lib.PREC_BF16 and S <= 224 and os.environ.get("BEVR_GATHER", "1") != "0"
 
 
+def slab_supported(precision, S) -> bool:
+    """Does the query-side backward over scattered keys run on the slab-stationary kernel (csrc/attn_slab_bwd_q.hip: a
+    workgroup owns a slab of rpe-table columns, the keys arrive sorted by their table column) instead of the query-tile
+    kernel bevr_attn_bwd_q?  16-bit operand modes, S <= 211 (7 row blocks of 31 queries and all their table rows in one
+    LDS column); BEVR_SLAB=0 turns it off (A/B timing).  Same results up to the order of the float atomics."""
+    return precision in (_lib.PREC_BF16, _lib.PREC_F16) and S <= 211 and os.environ.get("BEVR_SLAB", "1") != "0"
+
+
 class _AttnCore(torch.autograd.Function):
     """O = softmax(Q K^T + bias(a, b, table)) V in packed layouts (all inputs float32).
 
@@ -581,6 +589,22 @@ class _AttnCore(torch.autograd.Function):
                 _lib.check(L.bevr_attn_bwd_q_dropout(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair),
                                                      _ptr(dOe), _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT),
                                                      ctx.drop[0], ctx.drop[1], _stream()), "bevr_attn_bwd_q_dropout")
+            elif slab_supported(g.precision, g.S):
+                # keys sorted by table column b per problem-group; K and V rows gathered into that order (softmax and its
+                # gradients do not depend on the order of the keys; dK / dV come from the key-side kernel in the caller's)
+                order = kb[:, :g.N].argsort(1)
+                hpg = g.heads // g.groups
+                idx = order.view(g.n_prob, g.groups, 1, g.N).expand(-1, -1, hpg, -1).reshape(g.n_prob, g.heads, g.N, 1)
+                idx = idx.expand(-1, -1, -1, HEAD_DIM)
+                Ks, Vs = Ke[:, :, :g.N].gather(2, idx), Ve[:, :, :g.N].gather(2, idx)
+                sws = torch.empty(L.bevr_attn_slab_ws_bytes(C.byref(d)), device=dev, dtype=torch.uint8)
+                _lib.check(L.bevr_attn_slab_prep(C.byref(d), _ptr(ka), _ptr(kb), _ptr(order.to(torch.int32).contiguous()),
+                                                 _ptr(sws), _stream()), "bevr_attn_slab_prep")
+                _lib.check(KERNEL_TIMER.run("bevr_attn_slab_bwd_q", _attn_flops(g, 3), L.bevr_attn_slab_bwd_q, C.byref(d),
+                                            _ptr(Qe), _ptr(Ks), _ptr(Vs), _ptr(sws), _ptr(pair), _ptr(dOe), _ptr(LSE),
+                                            _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT), _stream(),
+                                            tag=_call_tag(g)), "bevr_attn_slab_bwd_q")
+                del Ks, Vs, sws
             else:
                 _lib.check(KERNEL_TIMER.run("bevr_attn_bwd_q", _attn_flops(g, 3), L.bevr_attn_bwd_q, C.byref(d), _ptr(Qe),
                                             _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair), _ptr(dOe),
@@ -958,8 +982,10 @@ class _Corr(torch.autograd.Function):
         D = torch.empty(n, m, device=cam.device, dtype=torch.float32)
         inc = torch.empty(n, device=cam.device, dtype=torch.float32)
         inm = torch.empty(m, device=cam.device, dtype=torch.float32)
-        _lib.check(_lib.lib().bevr_corr_fwd(_ptr(cam), _ptr(mp), _ptr(D), _ptr(inc), _ptr(inm), n, m, E,
-                                            int(normalize), _stream()), "bevr_corr_fwd")
+        same = cam.data_ptr() == mp.data_ptr() and n == m
+        _lib.check(KERNEL_TIMER.run("bevr_corr_fwd", 0.0, _lib.lib().bevr_corr_fwd, _ptr(cam), _ptr(mp), _ptr(D), _ptr(inc),
+                                    _ptr(inm), n, m, E, int(normalize), _stream(),
+                                    nbytes=4.0 * E * (n if same else n + m)), "bevr_corr_fwd")
         ctx.normalize = normalize
         ctx.save_for_backward(cam, mp, D, inc, inm)
         return D
@@ -970,10 +996,15 @@ class _Corr(torch.autograd.Function):
         n, E = cam.shape
         m = mp.shape[0]
         dcam, dmap = torch.empty_like(cam), torch.empty_like(mp)
-        _lib.check(_lib.lib().bevr_corr_bwd(_ptr(cam), _ptr(mp), _ptr(D), _ptr(dD.contiguous()), _ptr(inc), _ptr(inm),
-                                            _ptr(dcam), _ptr(dmap), n, m, E, int(ctx.normalize), _stream()),
+        # algorithmic (compulsory) HBM bytes: both operands read once, both gradients written once; one matrix correlated
+        # with itself (the retrieval losses): read once, and the two sides' SUM written once (csrc/corr.hip)
+        same = cam.data_ptr() == mp.data_ptr() and n == m and n <= 64 and E % 4 == 0
+        _lib.check(KERNEL_TIMER.run("bevr_corr_bwd", 0.0, _lib.lib().bevr_corr_bwd, _ptr(cam), _ptr(mp), _ptr(D),
+                                    _ptr(dD.contiguous()), _ptr(inc), _ptr(inm), _ptr(dcam), _ptr(dmap), n, m, E,
+                                    int(ctx.normalize), _stream(), nbytes=4.0 * E * (2 * n if same else 2 * (n + m))),
                    "bevr_corr_bwd")
-        return dcam, dmap, None
+        # same: dcam holds d/dcam + d/dmap (one gradient for the one tensor both arguments are)
+        return dcam, (None if same else dmap), None
 
 
 def pairwise_corr(cam: torch.Tensor, mp: torch.Tensor, normalize: bool = False) -> torch.Tensor:

@@ -46,7 +46,10 @@ extern "C" {
 /* 4: new entry points bevr_attn_tap_* (the projector-pinned keys without K / V), bevr_attn_gather_fwd (the forward over
  *    scattered keys with the bias on the matrix cores) and bevr_attn_*_dropout; nothing else
  *    changed. */
-#define BEVR_ABI_VERSION 4
+/* 5: new entry points bevr_attn_slab_ws_bytes / _slab_prep / _slab_bwd_q (the query-side backward cut along the rpe
+ *    table: a workgroup owns a slab of table columns); bevr_attn_tap_bwd_k's table operand is declared as what it always
+ *    was (the plain packed table, not the pair table); nothing else changed. */
+#define BEVR_ABI_VERSION 5
 
 enum {
   BEVR_OK = 0,
@@ -301,6 +304,30 @@ int bevr_attn_tap_bwd_k(const bevr_attn_desc* d, const void* G, const void* H, c
 int bevr_attn_gather_fwd(const bevr_attn_desc* d, const void* Q, const void* K, const void* V,
                          const void* key_ws, const void* table_pk, const float* mref, float* O, float* LSE,
                          int* flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SLAB entry points (csrc/attn_slab_bwd_q.hip): bevr_attn_bwd_q -- dQ and the rpe-table gradient of a key segment, same
+ * arithmetic per (query, key) pair, same operands and gradient semantics -- with the work cut along the TABLE: a work item
+ * owns a slab of <= 24 consecutive table columns of one (problem, head), all rows of them in LDS (values and 64-bit
+ * fixed-point gradient cells), and processes the pairs whose left tap column floor(j rx + b_n) falls into the slab; the
+ * keys are handed over SORTED BY b per problem, so those are one contiguous run per BEV column.  Every table cell leaves
+ * the workgroup once per item (no moving window, no flush traffic to speak of); dQ leaves as float atomics.
+ * 16-bit operand modes (BEVR_PREC_BF16, BEVR_PREC_F16), S <= 211; BEVR_E_SHAPE / BEVR_E_PRECISION otherwise (the caller
+ * keeps bevr_attn_bwd_q: bevrender_amd/ops.py:slab_supported).  Any key set is handled.
+ *   order  [n_prob*groups][N] int32: per problem-group, a permutation of 0..N-1 that sorts key_b ascending
+ *   Ks, Vs [n_prob][heads][N][32] E: the K / V rows IN THAT ORDER (row t of (prob, head) = key order[pg][t]), unpadded
+ *   slab_ws: bevr_attn_slab_ws_bytes(d) bytes (0: unsupported shape), written by bevr_attn_slab_prep, opaque; one
+ *           bevr_attn_slab_bwd_q launch per prep (the launch consumes the work list's counter)
+ *   Q, table_pair, dO, LSE, delta, grad_scale: as bevr_attn_bwd_q
+ *   dQ [n_prob][heads][Mp][32] float ACCUMULATED with float atomics (caller zeroes; bevr_attn_bwd_q WRITES its dQ)
+ *   dtable ACCUMULATED (as bevr_attn_bwd_q)
+ * ---------------------------------------------------------------------------------------------- */
+size_t bevr_attn_slab_ws_bytes(const bevr_attn_desc* d);
+int bevr_attn_slab_prep(const bevr_attn_desc* d, const float* key_a, const float* key_b, const int32_t* order,
+                        void* slab_ws, void* stream);
+int bevr_attn_slab_bwd_q(const bevr_attn_desc* d, const void* Q, const void* Ks, const void* Vs, const void* slab_ws,
+                         const float* table_pair, const void* dO, const float* LSE, const float* delta,
+                         const float* grad_scale, float* dQ, float* dtable, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bilinear feature sampling, align_corners=True, zero padding (grid_sample semantics).

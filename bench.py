@@ -451,7 +451,11 @@ def main():
         # scatter is memory-side float atomics, 4 taps per key)
         roof_hbm = []
         # bevr_kv_project: sampling + K | V projection + operand packing in one pass (feature map in, packed operands out)
-        for k in ("bevr_kv_project", "bevr_sample_fwd", "bevr_sample_bwd"):
+        # bevr_corr_fwd / _bwd: the ground <-> aerial correlation of the retrieval losses (train.py:551-572,
+        # loss/contrastive_loss.py:10-19): at B = 8 a (16 x 2.56 M) embedding matrix against itself -- the Gram on the f32
+        # matrix cores, HBM-bound (82 MB per operand set read once; the backward reads it again and writes the
+        # gradient once)
+        for k in ("bevr_kv_project", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_corr_fwd", "bevr_corr_bwd"):
             if k in ktimes and ktimes[k]["ms"] > 0:
                 v = ktimes[k]
                 gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9

@@ -36,6 +36,26 @@
 #include "attn_tile.h"
 #include "attn_tap.h"
 
+#ifdef BEVR_SPROF
+// phase stamps (make SPROF=1 OUTDIR=../lib_sprof; tools/prof_phases_slab.py): clocks summed over the emissions of wave 0
+// (a worker), wave 13 (the last worker) and the producer of every workgroup
+__device__ unsigned long long bevr_prof_slab[48];
+extern "C" int bevr_debug_prof_slab(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[48] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(bevr_prof_slab), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(bevr_prof_slab), 48 * 8);
+}
+__device__ __forceinline__ unsigned long long sprof_now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+  return t;
+}
+#define SPROF(var) const unsigned long long var = sprof_now()
+#define SPROF_ADD(i, v) pacc[i] += (v)
+#else
+#define SPROF(var)
+#define SPROF_ADD(i, v)
+#endif
+
 namespace {
 
 constexpr int SLAB_W_MAX = 24;     // owned table columns per slab (fewer when the rows of a large S leave less room)
@@ -93,8 +113,12 @@ __host__ __device__ inline int slab_count(const bevr_attn_desc& d, int sw) {
 __host__ __device__ inline int slab_chunks(int S) { return (S + SLAB_CH - 1) / SLAB_CH; }
 
 // workspace: SlabKey[PG][N] | kbeg[PG][n_slab][S] | kend[PG][n_slab][S] | items[n_ph * n_slab * n_chunk] (int4) | counters
+constexpr int SLAB_MAX_WG = 512;   // workgroups of the persistent launch (one per CU) the exchange scratch is sized for
+// dQ exchange: the two workers of a row block (one per 32-key half) hand their column sums to the producer through
+// memory; [workgroup][column parity][half][row block][16 values][64 lanes] floats
+constexpr size_t SLAB_XCH_WG = (size_t)2 * 2 * SNRB * 1024;
 struct SlabWs {
-  size_t off_beg, off_end, off_items, off_cnt, total;
+  size_t off_beg, off_end, off_items, off_cnt, off_xch, total;
   int n_slab, n_chunk, sw;
 };
 __host__ __device__ inline SlabWs slab_ws(const bevr_attn_desc& d) {
@@ -114,6 +138,8 @@ __host__ __device__ inline SlabWs slab_ws(const bevr_attn_desc& d) {
   o += (size_t)d.n_prob * d.heads * w.n_slab * w.n_chunk * 16;
   w.off_cnt = o;
   o += 256;
+  w.off_xch = o;
+  o += (size_t)SLAB_MAX_WG * SLAB_XCH_WG * 4;
   w.total = o;
   return w;
 }
@@ -213,7 +239,8 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
     const SlabKey* __restrict__ skeys, const int* __restrict__ kbeg, const int* __restrict__ kend,
     const int4* __restrict__ items, int* __restrict__ cnt, const char* __restrict__ table_pair,
     const char* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
-    const float* __restrict__ grad_scale, float* __restrict__ dQ, float* __restrict__ dtable, int n_slab, int sw, int R) {
+    const float* __restrict__ grad_scale, float* __restrict__ dQ, float* __restrict__ dtable, float* xch_all, int n_slab,
+    int sw, int R) {
   typedef SlabLds L;
   extern __shared__ __attribute__((aligned(256))) char lds[];
   // layout: vals (u32) | cells (u64) | staging x 2 | item slot
@@ -238,16 +265,23 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
   const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
   const float cfix = PREC == BEVR_PREC_F16 ? grad_scale[0] * grad_scale[4] : 1.f;
   const float dq_scale = PREC == BEVR_PREC_F16 ? grad_scale[4] * BEVR_LN2 : ginv;
+  float* xch = xch_all + (size_t)blockIdx.x * SLAB_XCH_WG;
+#ifdef BEVR_SPROF
+  unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
   for (;;) {
     // ---- next work item -------------------------------------------------------------------------------------------
     SLAB_BARRIER();                                   // everybody is done with the previous item's slot and slab
     if (tid == 0) item_slot[0] = atomicAdd(cnt + 1, 1);
     SLAB_BARRIER();
-    const int it = item_slot[0];
+    // read through readfirstlane: an LDS load is divergent to the compiler, and everything derived from the item (the
+    // problem's pointers, the slab's origin, the chunk's columns) would live in vector registers
+    const int it = __builtin_amdgcn_readfirstlane(item_slot[0]);
     if (it >= n_items) break;                         // uniform: every wave leaves here
     const int4 item = items[it];
-    const int ph = item.x, slab = item.y, chunk = item.z;
+    const int ph = __builtin_amdgcn_readfirstlane(item.x), slab = __builtin_amdgcn_readfirstlane(item.y),
+              chunk = __builtin_amdgcn_readfirstlane(item.z);
     const int prob = ph / d.heads, hd = ph % d.heads;
     const int pg = prob * d.groups + hd / hpg;
     const int qb = prob / d.q_div;
@@ -255,6 +289,7 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
     const int j0 = chunk * SLAB_CH, j1 = min(d.S, j0 + SLAB_CH);
     const char* tbl = table_pair + (size_t)hd * d.Wp * d.Hp * 8;
     float* dtb = dtable + (size_t)hd * d.Wp * Hq;
+    SPROF(ti0);
 
     // ---- the slab: values in, cells cleared -----------------------------------------------------------------------
     for (int u = tid; u < (sw + 1) * RP; u += STHREADS) {
@@ -272,6 +307,9 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       cells[u] = 0ull;
     }
     SLAB_BARRIER();
+    SPROF(ti1);
+    SPROF_ADD(12, ti1 - ti0);     // slab in
+    SPROF_ADD(15, 1);             // items
 
     if (producer) {
       // =========================================== PRODUCER ========================================================
@@ -316,7 +354,31 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       issue();
       int e = 0;
       int prev_c = -1;
+      // dQ of a finished column: the workers of both key halves left their sums in the exchange scratch (agent-scope
+      // stores, one barrier ago at least); summed here and added to dQ ONCE per (slab, column) -- half the atomic traffic
+      // of two flushes, and none of it in the workers.  A FIFO of two: a column that ended with emission e_last is
+      // complete when this wave has passed barrier e_last + 2.
+      int pj0 = -1, pe0 = 0, pp0 = 0, pj1 = -1, pe1 = 0, pp1 = 0, par = 0;
+      auto consume = [&](int jd, int pp) {
+        for (int rb2 = 0; rb2 < n_rb; ++rb2) {
+          const int qrow2 = rb2 * SQROWS + lq;
+          const bool live2 = lq < SQROWS && qrow2 < d.S;
+          const unsigned* x0p = reinterpret_cast<const unsigned*>(xch + ((size_t)(pp * 2 + 0) * SNRB + rb2) * 1024) + lane;
+          const unsigned* x1p = reinterpret_cast<const unsigned*>(xch + ((size_t)(pp * 2 + 1) * SNRB + rb2) * 1024) + lane;
+          float* row = dQ + ((size_t)ph * Mp + (size_t)jd * d.Sp + min(qrow2, d.S - 1)) * 32;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a = __builtin_bit_cast(float, __hip_atomic_load(x0p + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) +
+                            __builtin_bit_cast(float, __hip_atomic_load(x1p + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (live2) atomicAdd(row + 8 * (r >> 2) + 4 * hi + (r & 3), dq_scale * a);
+          }
+        }
+      };
       while (have) {
+        if (pj0 >= 0 && pe0 <= e - 2) {
+          consume(pj0, pp0);
+          pj0 = pj1; pe0 = pe1; pp0 = pp1; pj1 = -1;
+        }
         char* bb = stage + (e & 1) * L::BUF;
         const int c = cur_c, k0 = cur_k, kend_c = cur_end;
         const int j = j0 + c;
@@ -325,19 +387,27 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
         const bool last = !(lc < j1 - j0) || lc != c;
         const bool first = c != prev_c;
         prev_c = c;
+        SPROF(tp0);
+        const SlabKey sk_e = sk;
+        u32x4 kv_e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) kv_e[q] = kv[q];
+        SPROF(tp1);
+        SPROF_ADD(0, tp1 - tp0);      // producer: wait for this emission's loads
+        issue();              // the next emission's loads fly while this one is written and processed
         // ---- constants of (column j, key) ----
         {
-          const float tx = jrx + sk.b;
+          const float tx = jrx + sk_e.b;
           const float xf = floorf(tx);
           const int X = (int)xf;
           const bool live = (k0 + lane < kend_c) && X >= x0 && X < x0 + sw;
-          const float fx = tx - xf, fy = sk.fy;
+          const float fx = tx - xf, fy = sk_e.fy;
           SlabCK ck;
           if (live) {
             ck.wA = Half<PREC>::pack2((1.0f - fx) * (1.0f - fy), (1.0f - fx) * fy);
             ck.wB = Half<PREC>::pack2(fx * (1.0f - fy), fx * fy);
-            ck.row = sk.A + SLAB_ROW0;
-            ck.cell = (X - x0 + 1) * RP + ck.row;
+            ck.row = sk_e.A + SLAB_ROW0;
+            ck.cell = ((X - x0 + 1) * RP + ck.row) * 4;       // BYTE offset of the first tap's value entry
           } else {          // masked: first tap in the kill column => P = 0, dS = 0
             ck.wA = Half<PREC>::pack2(1.f, 0.f);
             ck.wB = 0u;
@@ -345,46 +415,71 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
             ck.cell = 0;
           }
           *reinterpret_cast<SlabCK*>(bb + L::OFF_CK + lane * 16) = ck;
-          const int amin = half_min_i(live ? sk.A : 0x7fffffff), amax = half_max_i(live ? sk.A : (int)0x80000000);
-          if (lane == 0) *reinterpret_cast<u32x4*>(bb + L::OFF_CT) = u32x4{(unsigned)((first ? SF_FIRST : 0) | (last ? SF_LAST : 0)), (unsigned)j, (unsigned)amin, (unsigned)amax};
-          if (lane == 32) *reinterpret_cast<u32x4*>(bb + L::OFF_CT + 16) = u32x4{(unsigned)amin, (unsigned)amax, 0u, 0u};
+          // per half: any live key; any live key whose rows leave the window for some row block (the clamped body)
+          const bool far = live && (sk_e.A + SLAB_ROW0 < 0 || sk_e.A > d.S - 1 + SLAB_PADR);
+          const unsigned long long lm = __ballot(live), fm = __ballot(far);
+          const unsigned hb = ((unsigned)lm != 0u ? 1u : 0u) | ((unsigned)(lm >> 32) != 0u ? 2u : 0u) |
+                              ((unsigned)fm != 0u ? 4u : 0u) | ((unsigned)(fm >> 32) != 0u ? 8u : 0u);
+          // the column after this one (the iterator is one emission ahead): the workers prefetch its Q / dO rows
+          const int jn = (last && have) ? j0 + cur_c + 1 : 0;
+          if (lane == 0)
+            *reinterpret_cast<u32x4*>(bb + L::OFF_CT) =
+                u32x4{(unsigned)((first ? SF_FIRST : 0) | (last ? SF_LAST : 0)) | (hb << 8), (unsigned)j | ((unsigned)jn << 16), 0u, 0u};
         }
         // ---- K and V rows ----
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int cid = lane + 64 * q;
-          *reinterpret_cast<u32x4*>(bb + (cid >> 2) * SKROW + (cid & 3) * 16) = kv[q];
-          *reinterpret_cast<u32x4*>(bb + L::OFF_V + (cid >> 2) * SKROW + (cid & 3) * 16) = kv[4 + q];
+          *reinterpret_cast<u32x4*>(bb + (cid >> 2) * SKROW + (cid & 3) * 16) = kv_e[q];
+          *reinterpret_cast<u32x4*>(bb + L::OFF_V + (cid >> 2) * SKROW + (cid & 3) * 16) = kv_e[4 + q];
         }
-        issue();              // the next emission's loads fly while the workers process this one
+        if (last) {           // this column's sums will be in the scratch two barriers from now
+          if (pj0 < 0) { pj0 = j; pe0 = e; pp0 = par; } else { pj1 = j; pe1 = e; pp1 = par; }
+          par ^= 1;
+        }
         ++e;
+        SPROF(tp2);
+        SPROF_ADD(1, tp2 - tp1);      // producer: constants, stores, next loads issued
         SLAB_BARRIER();
+        SPROF(tp3);
+        SPROF_ADD(2, tp3 - tp2);      // producer: waiting for the workers
+        SPROF_ADD(3, 1);
       }
       if (lane == 0) *reinterpret_cast<u32x4*>(stage + (e & 1) * L::BUF + L::OFF_CT) = u32x4{(unsigned)SF_DONE, 0u, 0u, 0u};
       SLAB_BARRIER();
       __builtin_amdgcn_s_setprio(0);
+      if (pj0 >= 0) consume(pj0, pp0);
+      if (pj1 >= 0) consume(pj1, pp1);
     } else {
       // =========================================== WORKERS =========================================================
       const bool active = rb < n_rb;
       const int i0 = rb * SQROWS;
       const int qrow = i0 + lq;
       const bool live = lq < SQROWS && qrow < d.S;
-      const int rowoff = i0 + lq;
+      const int rowoff4 = (i0 + lq) * 4;
       const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 64;
       const char* dOh = dO + ((size_t)ph * Mp) * 64;
+      const unsigned cells_off = (unsigned)(reinterpret_cast<char*>(cells) - lds);
       Frag<PREC> qf, dof;
-      float nl = 0.f, nd = 0.f;
-      int jcur = 0;
+      float nl = 0.f, nd = 0.f, lse_r = 0.f, dlt_r = 0.f;
+      int jpend = -1;
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 
-      auto load_column = [&](int j) {
+      // the rows of column j for this wave's row block: issued (raw) ...
+      auto issue_column = [&](int j) {
         const size_t mq = (size_t)j * d.Sp + min(qrow, d.S - 1);
         qf.load(Qh + mq * 64, hi);
         dof.load(dOh + mq * 64, hi);
-        const float lse = LSE[(size_t)ph * Mp + mq];
-        float dlt = delta[(size_t)ph * Mp + mq];
+        lse_r = LSE[(size_t)ph * Mp + mq];
+        dlt_r = delta[(size_t)ph * Mp + mq];
+        jpend = j;
+      };
+      // ... and made ready: lanes without a query compute on a copy of a real one with dO = delta = 0 (their dS is exactly
+      // 0); the fixed-point scale of the table-gradient cells is folded into dO and delta (attn_bwd_q.hip)
+      auto finish_column = [&]() {
+        float dlt = dlt_r;
         if (!live) {
           dof.v[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
           dof.v[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -402,24 +497,25 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
             dof.v[h] = __builtin_bit_cast(bf16x8, w);
           }
         }
-        nl = kp16 - lse;
+        nl = kp16 - lse_r;
         nd = -dlt;
-        jcur = j;
       };
+      int par = 0;
+      // the column's sum of this wave leaves through the exchange scratch (the producer adds the two halves' sums to dQ)
       auto flush_dq = [&]() {
-        if (live) {
-          float* row = dQ + ((size_t)ph * Mp + (size_t)jcur * d.Sp + qrow) * 32;
+        unsigned* xp = reinterpret_cast<unsigned*>(xch + ((size_t)(par * 2 + wh) * SNRB + rb) * 1024) + lane;
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(row + 8 * g4 + 4 * hi + k, dq_scale * dq[4 * g4 + k]);
+        for (int r = 0; r < 16; ++r) {
+          __hip_atomic_store(xp + r * 64, __builtin_bit_cast(unsigned, dq[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          dq[r] = 0.f;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        par ^= 1;
       };
 
-      // one 32-key half of an emission against this wave's 31 queries; CLAMP: the row index is clamped into the window
-      auto process = [&](const char* bb, auto clamp_tag) {
+      // one 32-key half of an emission against this wave's 31 queries; CLAMP: the row index is clamped into the window.
+      // jn >= 0: this is the column's last emission -- once the two products that read Q and dO are issued, the rows of
+      // column jn are requested INTO the same registers: they land under the key-row loop
+      auto process = [&](const char* bb, int jn, auto clamp_tag) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
         const SlabCK* pk = reinterpret_cast<const SlabCK*>(bb + L::OFF_CK) + wh * 32;
         f32x16 s, dp;
@@ -439,24 +535,28 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           vkf.load(bb + L::OFF_V + (wh * 32 + lq) * SKROW, hi);
           dp = mma_frag(vkf, dof, dp);      // dP^T - delta
         }
-        auto index = [&](const SlabCK& e) -> int {
-          if constexpr (CLAMP) return (e.cell - e.row) + max(0, min(e.row + rowoff, R - 1));
-          else return e.cell + rowoff;
+        SPROF(tq0);
+        if (jn >= 0) issue_column(jn);
+        // byte offset of the key's first tap VALUE for this lane's row; the gradient cell sits at twice that (8-byte
+        // cells behind the 4-byte values)
+        auto offset = [&](const SlabCK& e) -> int {
+          if constexpr (CLAMP) return (e.cell - 4 * e.row) + 4 * max(0, min(e.row + (rowoff4 >> 2), R - 1));
+          else return e.cell + rowoff4;
         };
-        auto read_tap = [&](int idx, unsigned& a, unsigned& b) {
-          a = vals[idx];
-          b = vals[idx + RP];
+        auto read_tap = [&](int off, unsigned& a, unsigned& b) {
+          a = *reinterpret_cast<const unsigned*>(lds + off);
+          b = *reinterpret_cast<const unsigned*>(lds + off + RP * 4);
         };
         SlabCK e0 = pk[crow(0, hi)], e1 = pk[crow(1, hi)];
-        int i0x = index(e0);
+        int o0 = offset(e0);
         unsigned ta, tb;
-        read_tap(i0x, ta, tb);
+        read_tap(o0, ta, tb);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           unsigned na = ta, nb = tb;
           SlabCK e2 = e1;
-          int i1x = i0x;
-          if (r + 1 < 16) { i1x = index(e1); read_tap(i1x, na, nb); }
+          int o1 = o0;
+          if (r + 1 < 16) { o1 = offset(e1); read_tap(o1, na, nb); }
           if (r + 2 < 16) e2 = pk[crow(r + 2, hi)];
           float sv = Half<PREC>::dot2(ta, e0.wA, s[r]);
           sv = Half<PREC>::dot2(tb, e0.wB, sv);
@@ -464,7 +564,7 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           if constexpr (PREC == BEVR_PREC_F16) ds *= c2_16;
           s[r] = ds;
           const float gb_ = slab_lane_below(ds);
-          unsigned long long* gp = cells + i0x;
+          unsigned long long* gp = reinterpret_cast<unsigned long long*>(lds + cells_off + 2 * o0);
           int iA, iB;
           if constexpr (PREC == BEVR_PREC_BF16) {
             const unsigned pr = pack_bf16x2(ds, gb_);
@@ -489,8 +589,10 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           }
           atomicAdd(gp, slab_from_int(iA));
           atomicAdd(gp + RP, slab_from_int(iB));
-          e0 = e1; e1 = e2; ta = na; tb = nb; i0x = i1x;
+          e0 = e1; e1 = e2; ta = na; tb = nb; o0 = o1;
         }
+        SPROF(tq1);
+        SPROF_ADD(4, tq1 - tq0);      // worker: the key-row loop
         {
           // A operand K^T[channel lq][key] for the accumulator contraction: element j of k-step s <-> key
           // 16 s + 8 (j >> 2) + 4 hi + (j & 3) (bevr_common.h: mma_acc_b), out of the row tile by transposed reads
@@ -501,36 +603,46 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           ktf.v[1] = lds_tr8(p + 16 * SKROW, 8 * SKROW);
           dq = mma_acc_b(ktf, s, dq);
         }
+        SPROF(tq2);
+        SPROF_ADD(5, tq2 - tq1);      // worker: dQ product
       };
 
       int e = 0;
       for (;;) {
+        SPROF(tw0);
         SLAB_BARRIER();
+        SPROF(tw1);
+        SPROF_ADD(0, tw1 - tw0);      // worker: barrier wait
         const char* bb = stage + (e & 1) * L::BUF;
         const u32x4 ct = *reinterpret_cast<const u32x4*>(bb + L::OFF_CT);
-        const unsigned flags = ct[0];
+        const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)ct[0]);
+        const unsigned jword = (unsigned)__builtin_amdgcn_readfirstlane((int)ct[1]);
         if (flags & SF_DONE) break;
         if (active) {
-          if (flags & SF_FIRST) load_column((int)ct[1]);
-          int amin = (int)ct[2], amax = (int)ct[3];
-          if (wh) {
-            const u32x4 c1 = *reinterpret_cast<const u32x4*>(bb + L::OFF_CT + 16);
-            amin = (int)c1[0];
-            amax = (int)c1[1];
+          const int j = (int)(jword & 0xffffu);
+          if (flags & SF_FIRST) {
+            if (jpend != j) issue_column(j);      // not prefetched (an item's first column; a half that was skipped)
+            finish_column();
           }
-          if (amax >= amin) {                              // the half has a live key
-            const bool inside = amin + SLAB_ROW0 >= 0 && amax <= d.S - 1 + SLAB_PADR;
-            if (inside) process(bb, std::false_type{});
-            else process(bb, std::true_type{});
+          const unsigned hb = (flags >> 8) >> wh;             // bit 0: this half has a live key; bit 2: one of them is far
+          if (hb & 1u) {
+            const int jn = (flags & SF_LAST) ? (int)(jword >> 16) - 1 : -1;
+            if (hb & 4u) process(bb, jn, std::true_type{});
+            else process(bb, jn, std::false_type{});
           }
           if (flags & SF_LAST) flush_dq();
         }
+        SPROF(tw2);
+        SPROF_ADD(1, tw2 - tw1);      // worker: the emission
+        SPROF_ADD(2, (flags >> 8) & 1u);
+        SPROF_ADD(3, 1);
         ++e;
       }
     }
 
     // ---- flush the slab: every cell once ----------------------------------------------------------------------------
     SLAB_BARRIER();
+    SPROF(tf0);
     for (int u = tid; u < (sw + 1) * RP; u += STHREADS) {
       const int c = u / RP, w = u - c * RP;
       const unsigned long long v = w < R ? cells[RP + u] : 0ull;
@@ -539,7 +651,15 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
         if (xc >= 0 && xc < d.Wp && yr >= 0 && yr < Hq) atomicAdd(dtb + (size_t)xc * Hq + yr, slab_to_float(v) * ginv);
       }
     }
+    SPROF(tf1);
+    SPROF_ADD(13, tf1 - tf0);     // slab out
   }
+#ifdef BEVR_SPROF
+  if (lane == 0 && (wave == 0 || wave == SNWORK - 1 || producer)) {
+    const int base = producer ? 32 : (wave ? 16 : 0);
+    for (int i = 0; i < 16; ++i) atomicAdd(&bevr_prof_slab[base + i], pacc[i]);
+  }
+#endif
 }
 
 template <int PREC>
@@ -556,7 +676,7 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* Ks, const void* V
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return BEVR_E_SHAPE;
-    n_cu = prop.multiProcessorCount;
+    n_cu = prop.multiProcessorCount < SLAB_MAX_WG ? prop.multiProcessorCount : SLAB_MAX_WG;
   }
   const int R = slab_rows(d.S);
   const size_t lds = slab_lds_bytes(d.S, w.sw);
@@ -571,7 +691,8 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* Ks, const void* V
                      (const char*)Ks, (const char*)Vs, reinterpret_cast<const SlabKey*>(base),
                      reinterpret_cast<const int*>(base + w.off_beg), reinterpret_cast<const int*>(base + w.off_end),
                      reinterpret_cast<const int4*>(base + w.off_items), cnt, (const char*)table_pair, (const char*)dO,
-                     LSE, delta, grad_scale, dQ, dtable, w.n_slab, w.sw, R);
+                     LSE, delta, grad_scale, dQ, dtable, reinterpret_cast<float*>(const_cast<char*>(base) + w.off_xch),
+                     w.n_slab, w.sw, R);
   return (int)hipGetLastError();
 }
 

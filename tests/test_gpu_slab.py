@@ -2,9 +2,13 @@
 replaces on the product path (bevr_attn_bwd_q) and against the oracle's materialised attention
 (reference model/SCA_deform_attn.py:331-413 / model/TSA_deform_attn.py:245-333 differentiated by autograd).
 
-Both kernels evaluate the same arithmetic per (query, key) pair -- the same 16-bit operands, the same packed tap weights,
-the same 64-bit fixed-point table-gradient cells -- so dQ and d(table) must agree to the order of their float additions:
-the limits here are 50x tighter than the bf16 limits against the oracle.  Cases: ragged sizes, several row blocks, a
+Both kernels evaluate the same arithmetic per (query, key) pair -- the same 16-bit operands, 16-bit packed tap weights,
+64-bit fixed-point table-gradient cells -- up to ONE rounding: the table column coordinate is j rx + b here and
+j rx + (b - region origin) there, so a tap weight can round to the neighbouring 16-bit value (2^-9 of the weight in bf16,
+2^-12 in fp16, on some pairs).  Observed differences: bf16 8e-5 ... 4e-3, fp16 3e-5 ... 6e-4 of the largest entry -- the size
+of the modes' own errors.  So the A/B limits are the modes' (1e-2 / 2e-3), and what pins the kernel is the second test:
+against the float64 oracle the slab kernel must be as accurate as the query-tile kernel (within 1.5x + a floor) and inside
+half the bf16 limit of tests/test_gpu_ops.py.  Cases: ragged sizes, several row blocks, a
 table wider than a slab by two orders of magnitude, channel groups, keys far outside the table (the clamped body), a
 single key, fp16."""
 import os
@@ -70,19 +74,22 @@ def test_slab_bwd_q_agrees_with_the_query_tile_kernel(name, prec):
     o1, dq1, dt1, dkv1, dp1 = _run(ins, h, g, V, prec, slab=True)
     o0, dq0, dt0, dkv0, dp0 = _run(ins, h, g, V, prec, slab=False)
     assert torch.equal(o1, o0)                      # the forward does not depend on the switch
-    assert torch.equal(dkv1, dkv0) and torch.equal(dp1, dp0)      # nor does the key side
+    # nor does the key side (float atomics in the position gradient: equal up to their order)
+    assert rel_err(dkv1, dkv0) < 1e-5 and rel_err(dp1, dp0) < 1e-4
     e_q, e_t = rel_err(dq1, dq0), rel_err(dt1, dt0)
     print(f"[slab vs tile {name} prec={prec}] dQ {e_q:.2e} d(table) {e_t:.2e}")
-    assert e_q < 2e-4 and e_t < 2e-4, (e_q, e_t)
+    lim = 1e-2 if prec == _lib.PREC_BF16 else 2e-3
+    assert e_q < lim and e_t < lim, (e_q, e_t)
     assert dt1.abs().sum() > 0 or N == 1
 
 
-@pytest.mark.parametrize("name", ["sca_small", "far_keys", "groups"])
-def test_slab_bwd_q_against_the_oracle(name):
-    """the oracle's materialised attention in float64, the bf16 mode's limits (tests/test_gpu_ops.py)"""
+@pytest.mark.parametrize("name", ["sca_small", "ragged", "three_row_blocks", "far_keys", "groups", "wide_table"])
+def test_slab_bwd_q_is_as_accurate_as_the_query_tile_kernel_against_the_oracle(name):
+    """the oracle's materialised attention in float64; bf16 operands on both kernels"""
     B, V, C, h, g, S, N, Wt, extra = CASES[name]
     ins = _problem(B, V, C, h, g, S, N, Wt, seed=3 + S, **extra)
-    _, dq, dt, _, _ = _run(ins, h, g, V, _lib.PREC_BF16, slab=True)
+    _, dq1, dt1, _, _ = _run(ins, h, g, V, _lib.PREC_BF16, slab=True)
+    _, dq0, dt0, _, _ = _run(ins, h, g, V, _lib.PREC_BF16, slab=False)
     query, kv, pos, table = (t.clone().double().requires_grad_(True) for t in ins)
     c = C // h
     outs = []
@@ -95,6 +102,8 @@ def test_slab_bwd_q_against_the_oracle(name):
     want = torch.stack(outs, 0)
     cot = torch.randn(want.shape, generator=torch.Generator().manual_seed(77)).double()
     want.backward(cot)
-    e_q, e_t = rel_err(dq.cpu().double(), query.grad), rel_err(dt.cpu().double(), table.grad)
-    print(f"[slab vs oracle {name}] dQ {e_q:.2e} d(table) {e_t:.2e}")
-    assert e_q < 3e-2 and e_t < 3e-2, (e_q, e_t)
+    e1 = (rel_err(dq1.cpu().double(), query.grad), rel_err(dt1.cpu().double(), table.grad))
+    e0 = (rel_err(dq0.cpu().double(), query.grad), rel_err(dt0.cpu().double(), table.grad))
+    print(f"[vs oracle {name}] slab dQ {e1[0]:.2e} d(table) {e1[1]:.2e} | tile dQ {e0[0]:.2e} d(table) {e0[1]:.2e}")
+    for a, b in zip(e1, e0):
+        assert a < 1.5e-2 and a < 1.5 * b + 1e-3, (e1, e0)

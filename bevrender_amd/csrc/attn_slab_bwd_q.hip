@@ -363,14 +363,19 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
         for (int rb2 = 0; rb2 < n_rb; ++rb2) {
           const int qrow2 = rb2 * SQROWS + lq;
           const bool live2 = lq < SQROWS && qrow2 < d.S;
-          const unsigned* x0p = reinterpret_cast<const unsigned*>(xch + ((size_t)(pp * 2 + 0) * SNRB + rb2) * 1024) + lane;
-          const unsigned* x1p = reinterpret_cast<const unsigned*>(xch + ((size_t)(pp * 2 + 1) * SNRB + rb2) * 1024) + lane;
+          const float* x0p = xch + ((size_t)(pp * 2 + 0) * SNRB + rb2) * 1024 + lane;
+          const float* x1p = xch + ((size_t)(pp * 2 + 1) * SNRB + rb2) * 1024 + lane;
           float* row = dQ + ((size_t)ph * Mp + (size_t)jd * d.Sp + min(qrow2, d.S - 1)) * 32;
+          // all 32 loads of the row block in flight before the first add (one memory latency per row block, not 16)
+          float a[16], b[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float a = __builtin_bit_cast(float, __hip_atomic_load(x0p + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) +
-                            __builtin_bit_cast(float, __hip_atomic_load(x1p + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (live2) atomicAdd(row + 8 * (r >> 2) + 4 * hi + (r & 3), dq_scale * a);
+            a[r] = __hip_atomic_load(x0p + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            b[r] = __hip_atomic_load(x1p + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (live2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(row + 8 * (r >> 2) + 4 * hi + (r & 3), dq_scale * (a[r] + b[r]));
           }
         }
       };
@@ -460,53 +465,33 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 64;
       const char* dOh = dO + ((size_t)ph * Mp) * 64;
       const unsigned cells_off = (unsigned)(reinterpret_cast<char*>(cells) - lds);
+      // Q and dO fragments of this wave's rows: RE-READ for every emission (L2 hits: 4 KB per wave) right after the key-row
+      // loop of the emission before, into registers that are dead inside that loop -- kept across it they cost 16 of the
+      // 128 registers, and the allocator answered with scratch reloads on every emission (~2 000 clk each, phase stamps)
       Frag<PREC> qf, dof;
-      float nl = 0.f, nd = 0.f, lse_r = 0.f, dlt_r = 0.f;
-      int jpend = -1;
+      float lse_r = 0.f, dlt_r = 0.f;
+      int fragj = -1;          // the column whose rows sit (raw) in qf / dof / lse_r / dlt_r
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 
-      // the rows of column j for this wave's row block: issued (raw) ...
-      auto issue_column = [&](int j) {
+      auto issue_frags = [&](int j) {
         const size_t mq = (size_t)j * d.Sp + min(qrow, d.S - 1);
         qf.load(Qh + mq * 64, hi);
         dof.load(dOh + mq * 64, hi);
         lse_r = LSE[(size_t)ph * Mp + mq];
         dlt_r = delta[(size_t)ph * Mp + mq];
-        jpend = j;
-      };
-      // ... and made ready: lanes without a query compute on a copy of a real one with dO = delta = 0 (their dS is exactly
-      // 0); the fixed-point scale of the table-gradient cells is folded into dO and delta (attn_bwd_q.hip)
-      auto finish_column = [&]() {
-        float dlt = dlt_r;
-        if (!live) {
-          dof.v[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          dof.v[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          dlt = 0.f;
-        }
-        if constexpr (PREC != BEVR_PREC_F16) dlt *= gscale;
-        if constexpr (PREC == BEVR_PREC_BF16) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            u32x4 w = __builtin_bit_cast(u32x4, dof.v[h]);
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-              w[k] = pack_bf16x2(__builtin_bit_cast(float, w[k] << 16) * gscale,
-                                 __builtin_bit_cast(float, w[k] & 0xffff0000u) * gscale);
-            dof.v[h] = __builtin_bit_cast(bf16x8, w);
-          }
-        }
-        nl = kp16 - lse_r;
-        nd = -dlt;
+        fragj = j;
       };
       int par = 0;
       // the column's sum of this wave leaves through the exchange scratch (the producer adds the two halves' sums to dQ)
       auto flush_dq = [&]() {
-        unsigned* xp = reinterpret_cast<unsigned*>(xch + ((size_t)(par * 2 + wh) * SNRB + rb) * 1024) + lane;
+        // (float stores: bit-casting the ELEMENTS of a float vector is miscompiled by this ROCm -- element 0 for all, DESIGN
+        // section 3 -- and the first version of this exchange stored dq[0] and fifteen zeros)
+        float* xp = xch + ((size_t)(par * 2 + wh) * SNRB + rb) * 1024 + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          __hip_atomic_store(xp + r * 64, __builtin_bit_cast(unsigned, dq[r]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(xp + r * 64, dq[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           dq[r] = 0.f;
         }
         par ^= 1;
@@ -515,12 +500,17 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       // one 32-key half of an emission against this wave's 31 queries; CLAMP: the row index is clamped into the window.
       // jn >= 0: this is the column's last emission -- once the two products that read Q and dO are issued, the rows of
       // column jn are requested INTO the same registers: they land under the key-row loop
-      auto process = [&](const char* bb, int jn, auto clamp_tag) {
+      auto process = [&](const char* bb, int j, int jnext, auto clamp_tag) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
         const SlabCK* pk = reinterpret_cast<const SlabCK*>(bb + L::OFF_CK) + wh * 32;
+        if (fragj != j) issue_frags(j);     // an item's first emission for this wave, or a half that was skipped
         f32x16 s, dp;
         {
-          float a = nl, b = nd;
+          // lanes without a query compute on a copy of a real one with dO = delta = 0 (their dS is exactly 0); the
+          // fixed-point scale of the table-gradient cells is folded into dO and delta (attn_bwd_q.hip)
+          float dlt = live ? dlt_r : 0.f;
+          if constexpr (PREC != BEVR_PREC_F16) dlt *= gscale;
+          float a = kp16 - lse_r, b = -dlt;
           asm volatile("" : "+v"(a), "+v"(b));
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[r] = a; dp[r] = b; }
@@ -531,12 +521,23 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           s = mma_frag(kf, qf, s);          // S^T - LSE
         }
         {
-          Frag<PREC> vkf;
+          Frag<PREC> vkf, dos;
           vkf.load(bb + L::OFF_V + (wh * 32 + lq) * SKROW, hi);
-          dp = mma_frag(vkf, dof, dp);      // dP^T - delta
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            u32x4 w = __builtin_bit_cast(u32x4, dof.v[h]);
+            if constexpr (PREC == BEVR_PREC_BF16) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                w[k] = pack_bf16x2(__builtin_bit_cast(float, w[k] << 16) * gscale,
+                                   __builtin_bit_cast(float, w[k] & 0xffff0000u) * gscale);
+            }
+            if (!live) w = u32x4{0u, 0u, 0u, 0u};
+            dos.v[h] = __builtin_bit_cast(bf16x8, w);
+          }
+          dp = mma_frag(vkf, dos, dp);      // dP^T - delta
         }
         SPROF(tq0);
-        if (jn >= 0) issue_column(jn);
         // byte offset of the key's first tap VALUE for this lane's row; the gradient cell sits at twice that (8-byte
         // cells behind the 4-byte values)
         auto offset = [&](const SlabCK& e) -> int {
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
         }
         SPROF(tq1);
         SPROF_ADD(4, tq1 - tq0);      // worker: the key-row loop
+        if (jnext >= 0) issue_frags(jnext);   // the next emission's rows (this column's again, or the next column's)
         {
           // A operand K^T[channel lq][key] for the accumulator contraction: element j of k-step s <-> key
           // 16 s + 8 (j >> 2) + 4 hi + (j & 3) (bevr_common.h: mma_acc_b), out of the row tile by transposed reads
@@ -620,15 +622,11 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
         if (flags & SF_DONE) break;
         if (active) {
           const int j = (int)(jword & 0xffffu);
-          if (flags & SF_FIRST) {
-            if (jpend != j) issue_column(j);      // not prefetched (an item's first column; a half that was skipped)
-            finish_column();
-          }
           const unsigned hb = (flags >> 8) >> wh;             // bit 0: this half has a live key; bit 2: one of them is far
           if (hb & 1u) {
-            const int jn = (flags & SF_LAST) ? (int)(jword >> 16) - 1 : -1;
-            if (hb & 4u) process(bb, jn, std::true_type{});
-            else process(bb, jn, std::false_type{});
+            const int jnext = (flags & SF_LAST) ? (int)(jword >> 16) - 1 : j;
+            if (hb & 4u) process(bb, j, jnext, std::true_type{});
+            else process(bb, j, jnext, std::false_type{});
           }
           if (flags & SF_LAST) flush_dq();
         }

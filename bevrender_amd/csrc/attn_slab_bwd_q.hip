@@ -18,9 +18,11 @@
 //   * every table cell leaves the workgroup ONCE per (item): the flush is ~(sw + 1) x rows floats per item, < 1 GB per
 //     launch; what goes to memory instead is the slab's share of dQ, one float atomic per (query, channel) and
 //     (slab, column) -- 2 S S 128 B x n_slab per (problem, head);
-//   * the two 32-key halves of a 64-key emission run on different waves (14 workers = 2 halves x 7 row blocks of 31
-//     queries) and the staging, the per-(column, key) constants and the key bookkeeping on a PRODUCER wave, one
-//     emission ahead: one barrier per emission, no staging registers in the workers.
+//   * 7 worker waves, one per row block of 31 queries, each running BOTH 32-key halves of a 64-key emission as two
+//     interleaved dependency chains (8 waves per CU = 256 registers per wave: no spills; the first version, 14 workers of
+//     one half each at 128 registers, reloaded spilled fragments from scratch on every emission and needed an exchange
+//     to sum the two halves' dQ), and the staging, the per-(column, key) constants and the key bookkeeping on a PRODUCER
+//     wave, one emission ahead: one barrier per emission, no staging registers in the workers.
 // The price: K and V are re-streamed per slab (every pair belongs to one slab, every key to ~S sw / (Wt / rx) of them),
 // and a workgroup is the whole CU (~150 KB of LDS).
 //
@@ -38,7 +40,7 @@
 
 #ifdef BEVR_SPROF
 // phase stamps (make SPROF=1 OUTDIR=../lib_sprof; tools/prof_phases_slab.py): clocks summed over the emissions of wave 0
-// (a worker), wave 13 (the last worker) and the producer of every workgroup
+// (a worker), wave 6 (the last worker) and the producer of every workgroup
 __device__ unsigned long long bevr_prof_slab[48];
 extern "C" int bevr_debug_prof_slab(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[48] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(bevr_prof_slab), z, sizeof(z)); }
@@ -66,8 +68,8 @@ constexpr int SLAB_RP = 448;       // row PITCH of a slab column in entries: 7 x
 constexpr int SLAB_CH = 25;        // BEV columns per work item
 constexpr int SQROWS = 31;         // query rows per row block (lane 31 of a half: the 32nd table row, attn_bwd_q.hip)
 constexpr int SNRB = 7;            // row blocks per column (S <= 217)
-constexpr int SNWORK = 2 * SNRB;   // worker waves: half x row block
-constexpr int STHREADS = (SNWORK + 1) * 64;
+constexpr int SNWORK = SNRB;       // worker waves: one per row block, BOTH 32-key halves of an emission each
+constexpr int STHREADS = (SNWORK + 1) * 64;   // 8 waves = 2 per SIMD: 256 registers per wave (see the kernel)
 constexpr int SEK = 64;            // keys per emission
 constexpr int SKROW = 80;          // bytes per staged K / V row (64 + 16: conflict-free fragment reads)
 constexpr float SLAB_EPS = 0.02f;  // slack of the key runs (in table columns): the kernel's own floor() decides membership
@@ -113,12 +115,8 @@ __host__ __device__ inline int slab_count(const bevr_attn_desc& d, int sw) {
 __host__ __device__ inline int slab_chunks(int S) { return (S + SLAB_CH - 1) / SLAB_CH; }
 
 // workspace: SlabKey[PG][N] | kbeg[PG][n_slab][S] | kend[PG][n_slab][S] | items[n_ph * n_slab * n_chunk] (int4) | counters
-constexpr int SLAB_MAX_WG = 512;   // workgroups of the persistent launch (one per CU) the exchange scratch is sized for
-// dQ exchange: the two workers of a row block (one per 32-key half) hand their column sums to the producer through
-// memory; [workgroup][column parity][half][row block][16 values][64 lanes] floats
-constexpr size_t SLAB_XCH_WG = (size_t)2 * 2 * SNRB * 1024;
 struct SlabWs {
-  size_t off_beg, off_end, off_items, off_cnt, off_xch, total;
+  size_t off_beg, off_end, off_items, off_cnt, total;
   int n_slab, n_chunk, sw;
 };
 __host__ __device__ inline SlabWs slab_ws(const bevr_attn_desc& d) {
@@ -138,8 +136,6 @@ __host__ __device__ inline SlabWs slab_ws(const bevr_attn_desc& d) {
   o += (size_t)d.n_prob * d.heads * w.n_slab * w.n_chunk * 16;
   w.off_cnt = o;
   o += 256;
-  w.off_xch = o;
-  o += (size_t)SLAB_MAX_WG * SLAB_XCH_WG * 4;
   w.total = o;
   return w;
 }
@@ -239,8 +235,7 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
     const SlabKey* __restrict__ skeys, const int* __restrict__ kbeg, const int* __restrict__ kend,
     const int4* __restrict__ items, int* __restrict__ cnt, const char* __restrict__ table_pair,
     const char* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ delta,
-    const float* __restrict__ grad_scale, float* __restrict__ dQ, float* __restrict__ dtable, float* xch_all, int n_slab,
-    int sw, int R) {
+    const float* __restrict__ grad_scale, float* __restrict__ dQ, float* __restrict__ dtable, int n_slab, int sw, int R) {
   typedef SlabLds L;
   extern __shared__ __attribute__((aligned(256))) char lds[];
   // layout: vals (u32) | cells (u64) | staging x 2 | item slot
@@ -253,7 +248,7 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lq = lane & 31, hi = lane >> 5;
   const bool producer = wave == SNWORK;
-  const int wh = wave / SNRB, rb = wave % SNRB;      // worker: key half, row block
+  const int rb = wave;                               // worker: row block
   const int n_rb = slab_n_rb(d.S);
   const int Mp = d.S * d.Sp;
   const int Hq = d.Hp + 1;
@@ -265,7 +260,6 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
   const float kp16 = PREC == BEVR_PREC_F16 ? grad_scale[2] : 0.f, c2_16 = PREC == BEVR_PREC_F16 ? grad_scale[3] : 1.f;
   const float cfix = PREC == BEVR_PREC_F16 ? grad_scale[0] * grad_scale[4] : 1.f;
   const float dq_scale = PREC == BEVR_PREC_F16 ? grad_scale[4] * BEVR_LN2 : ginv;
-  float* xch = xch_all + (size_t)blockIdx.x * SLAB_XCH_WG;
 #ifdef BEVR_SPROF
   unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -354,36 +348,7 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       issue();
       int e = 0;
       int prev_c = -1;
-      // dQ of a finished column: the workers of both key halves left their sums in the exchange scratch (agent-scope
-      // stores, one barrier ago at least); summed here and added to dQ ONCE per (slab, column) -- half the atomic traffic
-      // of two flushes, and none of it in the workers.  A FIFO of two: a column that ended with emission e_last is
-      // complete when this wave has passed barrier e_last + 2.
-      int pj0 = -1, pe0 = 0, pp0 = 0, pj1 = -1, pe1 = 0, pp1 = 0, par = 0;
-      auto consume = [&](int jd, int pp) {
-        for (int rb2 = 0; rb2 < n_rb; ++rb2) {
-          const int qrow2 = rb2 * SQROWS + lq;
-          const bool live2 = lq < SQROWS && qrow2 < d.S;
-          const float* x0p = xch + ((size_t)(pp * 2 + 0) * SNRB + rb2) * 1024 + lane;
-          const float* x1p = xch + ((size_t)(pp * 2 + 1) * SNRB + rb2) * 1024 + lane;
-          float* row = dQ + ((size_t)ph * Mp + (size_t)jd * d.Sp + min(qrow2, d.S - 1)) * 32;
-          // all 32 loads of the row block in flight before the first add (one memory latency per row block, not 16)
-          float a[16], b[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            a[r] = __hip_atomic_load(x0p + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            b[r] = __hip_atomic_load(x1p + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (live2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(row + 8 * (r >> 2) + 4 * hi + (r & 3), dq_scale * (a[r] + b[r]));
-          }
-        }
-      };
       while (have) {
-        if (pj0 >= 0 && pe0 <= e - 2) {
-          consume(pj0, pp0);
-          pj0 = pj1; pe0 = pe1; pp0 = pp1; pj1 = -1;
-        }
         char* bb = stage + (e & 1) * L::BUF;
         const int c = cur_c, k0 = cur_k, kend_c = cur_end;
         const int j = j0 + c;
@@ -438,10 +403,6 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           *reinterpret_cast<u32x4*>(bb + (cid >> 2) * SKROW + (cid & 3) * 16) = kv_e[q];
           *reinterpret_cast<u32x4*>(bb + L::OFF_V + (cid >> 2) * SKROW + (cid & 3) * 16) = kv_e[4 + q];
         }
-        if (last) {           // this column's sums will be in the scratch two barriers from now
-          if (pj0 < 0) { pj0 = j; pe0 = e; pp0 = par; } else { pj1 = j; pe1 = e; pp1 = par; }
-          par ^= 1;
-        }
         ++e;
         SPROF(tp2);
         SPROF_ADD(1, tp2 - tp1);      // producer: constants, stores, next loads issued
@@ -453,8 +414,6 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       if (lane == 0) *reinterpret_cast<u32x4*>(stage + (e & 1) * L::BUF + L::OFF_CT) = u32x4{(unsigned)SF_DONE, 0u, 0u, 0u};
       SLAB_BARRIER();
       __builtin_amdgcn_s_setprio(0);
-      if (pj0 >= 0) consume(pj0, pp0);
-      if (pj1 >= 0) consume(pj1, pp1);
     } else {
       // =========================================== WORKERS =========================================================
       const bool active = rb < n_rb;
@@ -465,79 +424,88 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 64;
       const char* dOh = dO + ((size_t)ph * Mp) * 64;
       const unsigned cells_off = (unsigned)(reinterpret_cast<char*>(cells) - lds);
-      // Q and dO fragments of this wave's rows: RE-READ for every emission (L2 hits: 4 KB per wave) right after the key-row
-      // loop of the emission before, into registers that are dead inside that loop -- kept across it they cost 16 of the
-      // 128 registers, and the allocator answered with scratch reloads on every emission (~2 000 clk each, phase stamps)
       Frag<PREC> qf, dof;
-      float lse_r = 0.f, dlt_r = 0.f;
-      int fragj = -1;          // the column whose rows sit (raw) in qf / dof / lse_r / dlt_r
+      float nl = 0.f, nd = 0.f, lse_r = 0.f, dlt_r = 0.f;
+      int jcur = -1, jpend = -1;
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 
-      auto issue_frags = [&](int j) {
+      // the rows of column j for this wave's row block: issued (raw) ...
+      auto issue_column = [&](int j) {
         const size_t mq = (size_t)j * d.Sp + min(qrow, d.S - 1);
         qf.load(Qh + mq * 64, hi);
         dof.load(dOh + mq * 64, hi);
         lse_r = LSE[(size_t)ph * Mp + mq];
         dlt_r = delta[(size_t)ph * Mp + mq];
-        fragj = j;
+        jpend = j;
       };
-      int par = 0;
-      // the column's sum of this wave leaves through the exchange scratch (the producer adds the two halves' sums to dQ)
-      auto flush_dq = [&]() {
-        // (float stores: bit-casting the ELEMENTS of a float vector is miscompiled by this ROCm -- element 0 for all, DESIGN
-        // section 3 -- and the first version of this exchange stored dq[0] and fifteen zeros)
-        float* xp = xch + ((size_t)(par * 2 + wh) * SNRB + rb) * 1024 + lane;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          __hip_atomic_store(xp + r * 64, dq[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          dq[r] = 0.f;
+      // ... and made ready: lanes without a query compute on a copy of a real one with dO = delta = 0 (their dS is exactly
+      // 0); the fixed-point scale of the table-gradient cells is folded into dO and delta (attn_bwd_q.hip)
+      auto finish_column = [&]() {
+        float dlt = dlt_r;
+        if (!live) {
+          dof.v[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          dof.v[1] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          dlt = 0.f;
         }
-        par ^= 1;
-      };
-
-      // one 32-key half of an emission against this wave's 31 queries; CLAMP: the row index is clamped into the window.
-      // jn >= 0: this is the column's last emission -- once the two products that read Q and dO are issued, the rows of
-      // column jn are requested INTO the same registers: they land under the key-row loop
-      auto process = [&](const char* bb, int j, int jnext, auto clamp_tag) {
-        constexpr bool CLAMP = decltype(clamp_tag)::value;
-        const SlabCK* pk = reinterpret_cast<const SlabCK*>(bb + L::OFF_CK) + wh * 32;
-        if (fragj != j) issue_frags(j);     // an item's first emission for this wave, or a half that was skipped
-        f32x16 s, dp;
-        {
-          // lanes without a query compute on a copy of a real one with dO = delta = 0 (their dS is exactly 0); the
-          // fixed-point scale of the table-gradient cells is folded into dO and delta (attn_bwd_q.hip)
-          float dlt = live ? dlt_r : 0.f;
-          if constexpr (PREC != BEVR_PREC_F16) dlt *= gscale;
-          float a = kp16 - lse_r, b = -dlt;
-          asm volatile("" : "+v"(a), "+v"(b));
-#pragma unroll
-          for (int r = 0; r < 16; ++r) { s[r] = a; dp[r] = b; }
-        }
-        {
-          Frag<PREC> kf;
-          kf.load(bb + (wh * 32 + lq) * SKROW, hi);
-          s = mma_frag(kf, qf, s);          // S^T - LSE
-        }
-        {
-          Frag<PREC> vkf, dos;
-          vkf.load(bb + L::OFF_V + (wh * 32 + lq) * SKROW, hi);
+        if constexpr (PREC != BEVR_PREC_F16) dlt *= gscale;
+        if constexpr (PREC == BEVR_PREC_BF16) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             u32x4 w = __builtin_bit_cast(u32x4, dof.v[h]);
-            if constexpr (PREC == BEVR_PREC_BF16) {
 #pragma unroll
-              for (int k = 0; k < 4; ++k)
-                w[k] = pack_bf16x2(__builtin_bit_cast(float, w[k] << 16) * gscale,
-                                   __builtin_bit_cast(float, w[k] & 0xffff0000u) * gscale);
-            }
-            if (!live) w = u32x4{0u, 0u, 0u, 0u};
-            dos.v[h] = __builtin_bit_cast(bf16x8, w);
+            for (int k = 0; k < 4; ++k)
+              w[k] = pack_bf16x2(__builtin_bit_cast(float, w[k] << 16) * gscale,
+                                 __builtin_bit_cast(float, w[k] & 0xffff0000u) * gscale);
+            dof.v[h] = __builtin_bit_cast(bf16x8, w);
           }
-          dp = mma_frag(vkf, dos, dp);      // dP^T - delta
+        }
+        nl = kp16 - lse_r;
+        nd = -dlt;
+        jcur = jpend;
+      };
+      // one flush per (slab, column): this wave saw every key of the column's run
+      auto flush_dq = [&]() {
+        if (live) {
+          float* row = dQ + ((size_t)ph * Mp + (size_t)jcur * d.Sp + qrow) * 32;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd(row + 8 * g4 + 4 * hi + k, dq_scale * dq[4 * g4 + k]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+      };
+
+      // One emission -- BOTH 32-key halves -- against this wave's 31 queries.  The two halves are two independent
+      // dependency chains written side by side (h = 0, 1 in every step of the key-row loop): with two waves per SIMD the
+      // latency of a chain (LDS round trips: constants -> taps -> ... -> atomics) is covered by the other chain and the
+      // other wave, where the 14-wave version (one half per wave) needed 128-register waves that spilled.  CLAMP: the row
+      // index is clamped into the window.  jn >= 0: the column's last emission -- once the products that read Q and dO are
+      // issued, the rows of column jn are requested INTO the same registers: they land under the key-row loop.
+      auto process = [&](const char* bb, int jn, auto clamp_tag) {
+        constexpr bool CLAMP = decltype(clamp_tag)::value;
+        const SlabCK* pk = reinterpret_cast<const SlabCK*>(bb + L::OFF_CK);
+        f32x16 s[2], dp[2];
+        {
+          float a = nl, b = nd;
+          asm volatile("" : "+v"(a), "+v"(b));
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[h][r] = a; dp[h][r] = b; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          Frag<PREC> kf, vkf;
+          kf.load(bb + (h * 32 + lq) * SKROW, hi);
+          s[h] = mma_frag(kf, qf, s[h]);          // S^T - LSE
+          vkf.load(bb + L::OFF_V + (h * 32 + lq) * SKROW, hi);
+          dp[h] = mma_frag(vkf, dof, dp[h]);      // dP^T - delta
         }
         SPROF(tq0);
+        if (jn >= 0) issue_column(jn);
         // byte offset of the key's first tap VALUE for this lane's row; the gradient cell sits at twice that (8-byte
         // cells behind the 4-byte values)
         auto offset = [&](const SlabCK& e) -> int {
@@ -548,65 +516,83 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           a = *reinterpret_cast<const unsigned*>(lds + off);
           b = *reinterpret_cast<const unsigned*>(lds + off + RP * 4);
         };
-        SlabCK e0 = pk[crow(0, hi)], e1 = pk[crow(1, hi)];
-        int o0 = offset(e0);
-        unsigned ta, tb;
-        read_tap(o0, ta, tb);
+        SlabCK e0[2], e1[2];
+        int o0[2];
+        unsigned ta[2], tb[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          e0[h] = pk[h * 32 + crow(0, hi)];
+          e1[h] = pk[h * 32 + crow(1, hi)];
+          o0[h] = offset(e0[h]);
+          read_tap(o0[h], ta[h], tb[h]);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          unsigned na = ta, nb = tb;
-          SlabCK e2 = e1;
-          int o1 = o0;
-          if (r + 1 < 16) { o1 = offset(e1); read_tap(o1, na, nb); }
-          if (r + 2 < 16) e2 = pk[crow(r + 2, hi)];
-          float sv = Half<PREC>::dot2(ta, e0.wA, s[r]);
-          sv = Half<PREC>::dot2(tb, e0.wB, sv);
-          float ds = fast_exp2(sv) * dp[r];
-          if constexpr (PREC == BEVR_PREC_F16) ds *= c2_16;
-          s[r] = ds;
-          const float gb_ = slab_lane_below(ds);
-          unsigned long long* gp = reinterpret_cast<unsigned long long*>(lds + cells_off + 2 * o0);
-          int iA, iB;
-          if constexpr (PREC == BEVR_PREC_BF16) {
-            const unsigned pr = pack_bf16x2(ds, gb_);
-            asm("v_dot2_f32_bf16 %0, %2, %3, 0\n\t"
-                "v_dot2_f32_bf16 %1, %2, %4, 0\n\t"
-                "s_nop 2\n\t"
-                "v_cvt_rpi_i32_f32 %0, %0\n\t"
-                "v_cvt_rpi_i32_f32 %1, %1"
-                : "=&v"(iA), "=&v"(iB)
-                : "v"(pr), "v"(e0.wA), "v"(e0.wB));
-          } else {
-            const unsigned pr = Half<PREC>::pack2(ds, gb_);
-            asm("v_dot2_f32_f16 %0, %2, %3, 0\n\t"
-                "v_dot2_f32_f16 %1, %2, %4, 0\n\t"
-                "s_nop 2\n\t"
-                "v_mul_f32 %0, %0, %5\n\t"
-                "v_mul_f32 %1, %1, %5\n\t"
-                "v_cvt_rpi_i32_f32 %0, %0\n\t"
-                "v_cvt_rpi_i32_f32 %1, %1"
-                : "=&v"(iA), "=&v"(iB)
-                : "v"(pr), "v"(e0.wA), "v"(e0.wB), "v"(cfix));
+          unsigned na[2], nb[2];
+          SlabCK e2[2];
+          int o1[2];
+          // the LDS atomics are ordered memory operations for the compiler (it moves no load across them): the taps of key
+          // row r + 1 and the constants of r + 2, of BOTH halves, are requested before the adds of row r are issued
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            na[h] = ta[h]; nb[h] = tb[h]; e2[h] = e1[h]; o1[h] = o0[h];
+            if (r + 1 < 16) { o1[h] = offset(e1[h]); read_tap(o1[h], na[h], nb[h]); }
+            if (r + 2 < 16) e2[h] = pk[h * 32 + crow(r + 2, hi)];
           }
-          atomicAdd(gp, slab_from_int(iA));
-          atomicAdd(gp + RP, slab_from_int(iB));
-          e0 = e1; e1 = e2; ta = na; tb = nb; o0 = o1;
+          int iA[2], iB[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float sv = Half<PREC>::dot2(ta[h], e0[h].wA, s[h][r]);
+            sv = Half<PREC>::dot2(tb[h], e0[h].wB, sv);
+            float ds = fast_exp2(sv) * dp[h][r];
+            if constexpr (PREC == BEVR_PREC_F16) ds *= c2_16;
+            s[h][r] = ds;
+            const float gb_ = slab_lane_below(ds);
+            if constexpr (PREC == BEVR_PREC_BF16) {
+              const unsigned pr = pack_bf16x2(ds, gb_);
+              asm("v_dot2_f32_bf16 %0, %2, %3, 0\n\t"
+                  "v_dot2_f32_bf16 %1, %2, %4, 0\n\t"
+                  "s_nop 2\n\t"
+                  "v_cvt_rpi_i32_f32 %0, %0\n\t"
+                  "v_cvt_rpi_i32_f32 %1, %1"
+                  : "=&v"(iA[h]), "=&v"(iB[h])
+                  : "v"(pr), "v"(e0[h].wA), "v"(e0[h].wB));
+            } else {
+              const unsigned pr = Half<PREC>::pack2(ds, gb_);
+              asm("v_dot2_f32_f16 %0, %2, %3, 0\n\t"
+                  "v_dot2_f32_f16 %1, %2, %4, 0\n\t"
+                  "s_nop 2\n\t"
+                  "v_mul_f32 %0, %0, %5\n\t"
+                  "v_mul_f32 %1, %1, %5\n\t"
+                  "v_cvt_rpi_i32_f32 %0, %0\n\t"
+                  "v_cvt_rpi_i32_f32 %1, %1"
+                  : "=&v"(iA[h]), "=&v"(iB[h])
+                  : "v"(pr), "v"(e0[h].wA), "v"(e0[h].wB), "v"(cfix));
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            unsigned long long* gp = reinterpret_cast<unsigned long long*>(lds + cells_off + 2 * o0[h]);
+            atomicAdd(gp, slab_from_int(iA[h]));
+            atomicAdd(gp + RP, slab_from_int(iB[h]));
+            e0[h] = e1[h]; e1[h] = e2[h]; ta[h] = na[h]; tb[h] = nb[h]; o0[h] = o1[h];
+          }
         }
         SPROF(tq1);
         SPROF_ADD(4, tq1 - tq0);      // worker: the key-row loop
-        if (jnext >= 0) issue_frags(jnext);   // the next emission's rows (this column's again, or the next column's)
-        {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
           // A operand K^T[channel lq][key] for the accumulator contraction: element j of k-step s <-> key
           // 16 s + 8 (j >> 2) + 4 hi + (j & 3) (bevr_common.h: mma_acc_b), out of the row tile by transposed reads
           Frag<PREC> ktf;
           const int i16 = lane & 15, chalf = (lane >> 4) & 1;
-          const char* p = bb + (wh * 32 + 4 * hi + (i16 >> 2)) * SKROW + chalf * 32 + 8 * (i16 & 3);
+          const char* p = bb + (h * 32 + 4 * hi + (i16 >> 2)) * SKROW + chalf * 32 + 8 * (i16 & 3);
           ktf.v[0] = lds_tr8(p, 8 * SKROW);
           ktf.v[1] = lds_tr8(p + 16 * SKROW, 8 * SKROW);
-          dq = mma_acc_b(ktf, s, dq);
+          dq = mma_acc_b(ktf, s[h], dq);
         }
         SPROF(tq2);
-        SPROF_ADD(5, tq2 - tq1);      // worker: dQ product
+        SPROF_ADD(5, tq2 - tq1);      // worker: dQ products
       };
 
       int e = 0;
@@ -622,11 +608,15 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
         if (flags & SF_DONE) break;
         if (active) {
           const int j = (int)(jword & 0xffffu);
-          const unsigned hb = (flags >> 8) >> wh;             // bit 0: this half has a live key; bit 2: one of them is far
-          if (hb & 1u) {
-            const int jnext = (flags & SF_LAST) ? (int)(jword >> 16) - 1 : j;
-            if (hb & 4u) process(bb, j, jnext, std::true_type{});
-            else process(bb, j, jnext, std::false_type{});
+          if (flags & SF_FIRST) {
+            if (jpend != j) issue_column(j);      // not prefetched: an item's first column
+            finish_column();
+          }
+          const unsigned hb = flags >> 8;          // bits 0, 1: the halves with a live key; bits 2, 3: with a far one
+          if (hb & 3u) {
+            const int jn = (flags & SF_LAST) ? (int)(jword >> 16) - 1 : -1;
+            if (hb & 12u) process(bb, jn, std::true_type{});
+            else process(bb, jn, std::false_type{});
           }
           if (flags & SF_LAST) flush_dq();
         }
@@ -674,7 +664,7 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* Ks, const void* V
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return BEVR_E_SHAPE;
-    n_cu = prop.multiProcessorCount < SLAB_MAX_WG ? prop.multiProcessorCount : SLAB_MAX_WG;
+    n_cu = prop.multiProcessorCount;
   }
   const int R = slab_rows(d.S);
   const size_t lds = slab_lds_bytes(d.S, w.sw);
@@ -689,8 +679,7 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* Ks, const void* V
                      (const char*)Ks, (const char*)Vs, reinterpret_cast<const SlabKey*>(base),
                      reinterpret_cast<const int*>(base + w.off_beg), reinterpret_cast<const int*>(base + w.off_end),
                      reinterpret_cast<const int4*>(base + w.off_items), cnt, (const char*)table_pair, (const char*)dO,
-                     LSE, delta, grad_scale, dQ, dtable, reinterpret_cast<float*>(const_cast<char*>(base) + w.off_xch),
-                     w.n_slab, w.sw, R);
+                     LSE, delta, grad_scale, dQ, dtable, w.n_slab, w.sw, R);
   return (int)hipGetLastError();
 }
 

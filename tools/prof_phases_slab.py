@@ -15,7 +15,7 @@ exec(open(os.path.join(ROOT, "tools", "prof_sca.py")).read())
 torch.cuda.synchronize()
 L.bevr_debug_prof_slab(buf, 0)
 v = list(buf)
-for tag, b in (("worker wave 0", 0), ("worker wave 13", 16)):
+for tag, b in (("worker wave 0", 0), ("worker wave 6", 16)):
     n = max(1, v[b + 3])
     print(f"{tag}: emissions {v[b+3]} (with a live key in half 0: {v[b+2]}), items {v[b+15]}; clk per emission: "
           f"barrier wait {v[b]/n:.0f}, emission body {v[b+1]/n:.0f} (key-row loop {v[b+4]/n:.0f}, dQ product {v[b+5]/n:.0f}); "

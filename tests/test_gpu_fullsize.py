@@ -631,8 +631,9 @@ def test_tsa_module_bev200_rows(prec):
 
 def test_cfg5_tsa_module_bev400_fp16_rows():
     """BASELINE config 5 at the module level: TSADeformableAttention at S = 400 (N = 160 000 grid keys), fp16 operands,
-    against oracle.tsa_forward(rows=...) in float64 on 32 BEV positions."""
-    _tsa_module_rows(_lib.PREC_F16, 400, 32)
+    against oracle.tsa_forward(rows=...) in float64 on 128 BEV positions (with 32 the offset head's gradients -- sums of
+    d(pos) over the keys, which jumps at kinks -- were 2.5e-2 off against their 2e-2 limit: too few rows for that sum)."""
+    _tsa_module_rows(_lib.PREC_F16, 400, 128)
 
 
 def _tsa_module_rows(prec, S, n_rows):

@@ -417,6 +417,9 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
     } else {
       // =========================================== WORKERS =========================================================
       const bool active = rb < n_rb;
+      // waves 4 .. 6 share a SIMD with waves 0 .. 2, and the issue arbitration favours the older wave: the phase stamps had
+      // wave 6's key-row loop 26 % longer than wave 0's, and the barrier waits for the slowest
+      if (wave >= 4) __builtin_amdgcn_s_setprio(1);
       const int i0 = rb * SQROWS;
       const int qrow = i0 + lq;
       const bool live = lq < SQROWS && qrow < d.S;
@@ -478,15 +481,17 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
         for (int r = 0; r < 16; ++r) dq[r] = 0.f;
       };
 
-      // One emission -- BOTH 32-key halves -- against this wave's 31 queries.  The two halves are two independent
-      // dependency chains written side by side (h = 0, 1 in every step of the key-row loop): with two waves per SIMD the
-      // latency of a chain (LDS round trips: constants -> taps -> ... -> atomics) is covered by the other chain and the
-      // other wave, where the 14-wave version (one half per wave) needed 128-register waves that spilled.  CLAMP: the row
-      // index is clamped into the window.  jn >= 0: the column's last emission -- once the products that read Q and dO are
-      // issued, the rows of column jn are requested INTO the same registers: they land under the key-row loop.
+      // One emission -- both 32-key halves, one after the other -- against this wave's 31 queries.  The key-row loop of a
+      // half runs TWO key rows per step (rows r and r + 8: two independent dependency chains written side by side): with
+      // two waves per SIMD the latency of a chain (LDS round trips: constants -> taps -> ... -> atomics) is covered by
+      // the other chain and the other wave, where the 14-wave version (one half per wave, one row per step) needed
+      // 128-register waves that spilled.  The matrix products are placed so that they run UNDER a loop: S and dP of the
+      // second half are issued before the first half's loop, the first half's dQ product before the second half's loop.
+      // CLAMP: the row index is clamped into the window.  jn >= 0: the column's last emission -- once the products that
+      // read Q and dO are issued, the rows of column jn are requested INTO the same registers.
       auto process = [&](const char* bb, int jn, auto clamp_tag) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
-        const SlabCK* pk = reinterpret_cast<const SlabCK*>(bb + L::OFF_CK);
+        const SlabCK* pk0 = reinterpret_cast<const SlabCK*>(bb + L::OFF_CK);
         f32x16 s[2], dp[2];
         {
           float a = nl, b = nd;
@@ -504,8 +509,9 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           vkf.load(bb + L::OFF_V + (h * 32 + lq) * SKROW, hi);
           dp[h] = mma_frag(vkf, dof, dp[h]);      // dP^T - delta
         }
-        SPROF(tq0);
         if (jn >= 0) issue_column(jn);
+        __builtin_amdgcn_sched_barrier(0);
+        SPROF(tq0);
         // byte offset of the key's first tap VALUE for this lane's row; the gradient cell sits at twice that (8-byte
         // cells behind the 4-byte values)
         auto offset = [&](const SlabCK& e) -> int {
@@ -516,72 +522,7 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           a = *reinterpret_cast<const unsigned*>(lds + off);
           b = *reinterpret_cast<const unsigned*>(lds + off + RP * 4);
         };
-        SlabCK e0[2], e1[2];
-        int o0[2];
-        unsigned ta[2], tb[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          e0[h] = pk[h * 32 + crow(0, hi)];
-          e1[h] = pk[h * 32 + crow(1, hi)];
-          o0[h] = offset(e0[h]);
-          read_tap(o0[h], ta[h], tb[h]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          unsigned na[2], nb[2];
-          SlabCK e2[2];
-          int o1[2];
-          // the LDS atomics are ordered memory operations for the compiler (it moves no load across them): the taps of key
-          // row r + 1 and the constants of r + 2, of BOTH halves, are requested before the adds of row r are issued
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            na[h] = ta[h]; nb[h] = tb[h]; e2[h] = e1[h]; o1[h] = o0[h];
-            if (r + 1 < 16) { o1[h] = offset(e1[h]); read_tap(o1[h], na[h], nb[h]); }
-            if (r + 2 < 16) e2[h] = pk[h * 32 + crow(r + 2, hi)];
-          }
-          int iA[2], iB[2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            float sv = Half<PREC>::dot2(ta[h], e0[h].wA, s[h][r]);
-            sv = Half<PREC>::dot2(tb[h], e0[h].wB, sv);
-            float ds = fast_exp2(sv) * dp[h][r];
-            if constexpr (PREC == BEVR_PREC_F16) ds *= c2_16;
-            s[h][r] = ds;
-            const float gb_ = slab_lane_below(ds);
-            if constexpr (PREC == BEVR_PREC_BF16) {
-              const unsigned pr = pack_bf16x2(ds, gb_);
-              asm("v_dot2_f32_bf16 %0, %2, %3, 0\n\t"
-                  "v_dot2_f32_bf16 %1, %2, %4, 0\n\t"
-                  "s_nop 2\n\t"
-                  "v_cvt_rpi_i32_f32 %0, %0\n\t"
-                  "v_cvt_rpi_i32_f32 %1, %1"
-                  : "=&v"(iA[h]), "=&v"(iB[h])
-                  : "v"(pr), "v"(e0[h].wA), "v"(e0[h].wB));
-            } else {
-              const unsigned pr = Half<PREC>::pack2(ds, gb_);
-              asm("v_dot2_f32_f16 %0, %2, %3, 0\n\t"
-                  "v_dot2_f32_f16 %1, %2, %4, 0\n\t"
-                  "s_nop 2\n\t"
-                  "v_mul_f32 %0, %0, %5\n\t"
-                  "v_mul_f32 %1, %1, %5\n\t"
-                  "v_cvt_rpi_i32_f32 %0, %0\n\t"
-                  "v_cvt_rpi_i32_f32 %1, %1"
-                  : "=&v"(iA[h]), "=&v"(iB[h])
-                  : "v"(pr), "v"(e0[h].wA), "v"(e0[h].wB), "v"(cfix));
-            }
-          }
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            unsigned long long* gp = reinterpret_cast<unsigned long long*>(lds + cells_off + 2 * o0[h]);
-            atomicAdd(gp, slab_from_int(iA[h]));
-            atomicAdd(gp + RP, slab_from_int(iB[h]));
-            e0[h] = e1[h]; e1[h] = e2[h]; ta[h] = na[h]; tb[h] = nb[h]; o0[h] = o1[h];
-          }
-        }
-        SPROF(tq1);
-        SPROF_ADD(4, tq1 - tq0);      // worker: the key-row loop
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        auto dq_product = [&](int h) {
           // A operand K^T[channel lq][key] for the accumulator contraction: element j of k-step s <-> key
           // 16 s + 8 (j >> 2) + 4 hi + (j & 3) (bevr_common.h: mma_acc_b), out of the row tile by transposed reads
           Frag<PREC> ktf;
@@ -590,9 +531,81 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           ktf.v[0] = lds_tr8(p, 8 * SKROW);
           ktf.v[1] = lds_tr8(p + 16 * SKROW, 8 * SKROW);
           dq = mma_acc_b(ktf, s[h], dq);
+        };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const SlabCK* pk = pk0 + h * 32;
+          // chain c walks the key rows c * 8 + 0 .. 7 of the accumulator tile
+          SlabCK e0[2], e1[2];
+          int o0[2];
+          unsigned ta[2], tb[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            e0[c] = pk[crow(8 * c, hi)];
+            e1[c] = pk[crow(8 * c + 1, hi)];
+            o0[c] = offset(e0[c]);
+            read_tap(o0[c], ta[c], tb[c]);
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            unsigned na[2], nb[2];
+            SlabCK e2[2];
+            int o1[2];
+            // the LDS atomics are ordered memory operations for the compiler (it moves no load across them): the taps of
+            // the next key row and the constants of the one after, of BOTH chains, are requested before the adds of this
+            // step are issued
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              na[c] = ta[c]; nb[c] = tb[c]; e2[c] = e1[c]; o1[c] = o0[c];
+              if (r + 1 < 8) { o1[c] = offset(e1[c]); read_tap(o1[c], na[c], nb[c]); }
+              if (r + 2 < 8) e2[c] = pk[crow(8 * c + r + 2, hi)];
+            }
+            int iA[2], iB[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int row = 8 * c + r;
+              float sv = Half<PREC>::dot2(ta[c], e0[c].wA, s[h][row]);
+              sv = Half<PREC>::dot2(tb[c], e0[c].wB, sv);
+              float ds = fast_exp2(sv) * dp[h][row];
+              if constexpr (PREC == BEVR_PREC_F16) ds *= c2_16;
+              s[h][row] = ds;
+              const float gb_ = slab_lane_below(ds);
+              if constexpr (PREC == BEVR_PREC_BF16) {
+                const unsigned pr = pack_bf16x2(ds, gb_);
+                asm("v_dot2_f32_bf16 %0, %2, %3, 0\n\t"
+                    "v_dot2_f32_bf16 %1, %2, %4, 0\n\t"
+                    "s_nop 2\n\t"
+                    "v_cvt_rpi_i32_f32 %0, %0\n\t"
+                    "v_cvt_rpi_i32_f32 %1, %1"
+                    : "=&v"(iA[c]), "=&v"(iB[c])
+                    : "v"(pr), "v"(e0[c].wA), "v"(e0[c].wB));
+              } else {
+                const unsigned pr = Half<PREC>::pack2(ds, gb_);
+                asm("v_dot2_f32_f16 %0, %2, %3, 0\n\t"
+                    "v_dot2_f32_f16 %1, %2, %4, 0\n\t"
+                    "s_nop 2\n\t"
+                    "v_mul_f32 %0, %0, %5\n\t"
+                    "v_mul_f32 %1, %1, %5\n\t"
+                    "v_cvt_rpi_i32_f32 %0, %0\n\t"
+                    "v_cvt_rpi_i32_f32 %1, %1"
+                    : "=&v"(iA[c]), "=&v"(iB[c])
+                    : "v"(pr), "v"(e0[c].wA), "v"(e0[c].wB), "v"(cfix));
+              }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              unsigned long long* gp = reinterpret_cast<unsigned long long*>(lds + cells_off + 2 * o0[c]);
+              atomicAdd(gp, slab_from_int(iA[c]));
+              atomicAdd(gp + RP, slab_from_int(iB[c]));
+              e0[c] = e1[c]; e1[c] = e2[c]; ta[c] = na[c]; tb[c] = nb[c]; o0[c] = o1[c];
+            }
+          }
+          // the half's dQ product: issued here, it runs under the other half's loop (h = 0) or the barrier wait (h = 1)
+          dq_product(h);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        SPROF(tq2);
-        SPROF_ADD(5, tq2 - tq1);      // worker: dQ products
+        SPROF(tq1);
+        SPROF_ADD(4, tq1 - tq0);      // worker: the key-row loops and dQ products
       };
 
       int e = 0;

@@ -379,12 +379,18 @@ def gather_supported(precision, S) -> bool:
     return precision == _lib.PREC_BF16 and S <= 224 and os.environ.get("BEVR_GATHER", "1") != "0"
 
 
-def slab_supported(precision, S) -> bool:
+def slab_supported(precision, S, Wt=None) -> bool:
     """Does the query-side backward over scattered keys run on the slab-stationary kernel (csrc/attn_slab_bwd_q.hip: a
     workgroup owns a slab of rpe-table columns, the keys arrive sorted by their table column) instead of the query-tile
     kernel bevr_attn_bwd_q?  16-bit operand modes, S <= 211 (7 row blocks of 31 queries and all their table rows in one
-    LDS column); BEVR_SLAB=0 turns it off (A/B timing).  Same results up to the order of the float atomics."""
-    return precision in (_lib.PREC_BF16, _lib.PREC_F16) and S <= 211 and os.environ.get("BEVR_SLAB", "1") != "0"
+    LDS column).  With Wt given: only tables at least twice as wide as TSA's (rx >= 2 table columns per BEV column: SCA) --
+    on TSA's regular key grid the query-tile kernel's window hardly moves and it is the faster one (0.91 against 0.77 T
+    pairs/s on the benchmark, profiles/r05_*); BEVR_SLAB=0 turns the kernel off, BEVR_SLAB=2 forces it for every table
+    (A/B timing, tests).  Same results up to the order of the float atomics and one rounding of the tap weights."""
+    mode = os.environ.get("BEVR_SLAB", "1")
+    if mode == "0" or precision not in (_lib.PREC_BF16, _lib.PREC_F16) or S > 211:
+        return False
+    return mode == "2" or Wt is None or Wt - 1 >= 4 * (S - 1)
 
 
 class _AttnCore(torch.autograd.Function):
@@ -589,7 +595,7 @@ class _AttnCore(torch.autograd.Function):
                 _lib.check(L.bevr_attn_bwd_q_dropout(C.byref(d), _ptr(Qe), _ptr(Ke), _ptr(Kt), _ptr(Ve), _ptr(key_ws), _ptr(pair),
                                                      _ptr(dOe), _ptr(LSE), _ptr(delta), _ptr(gscale), _ptr(dQ), _ptr(dT),
                                                      ctx.drop[0], ctx.drop[1], _stream()), "bevr_attn_bwd_q_dropout")
-            elif slab_supported(g.precision, g.S):
+            elif slab_supported(g.precision, g.S, g.Wt):
                 # keys sorted by table column b per problem-group; K and V rows gathered into that order (softmax and its
                 # gradients do not depend on the order of the keys; dK / dV come from the key-side kernel in the caller's)
                 order = kb[:, :g.N].argsort(1)

@@ -40,7 +40,7 @@ def _problem(B, V, C, h, g, S, N, Wt, seed, spread=1.05, far=0.0):
 
 
 def _run(ins, h, g, V, prec, slab):
-    os.environ["BEVR_SLAB"] = "1" if slab else "0"
+    os.environ["BEVR_SLAB"] = "2" if slab else "0"      # 2: the slab kernel for every table width (ops.slab_supported)
     try:
         query, kv, pos, table = (t.clone().to(DEV).requires_grad_(True) for t in ins)
         out = ops.attention_core(query, None, None, pos, table, heads=h, groups=g, views=V, precision=prec, kv=kv)

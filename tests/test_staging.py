@@ -74,7 +74,20 @@ def test_bf16_staging_full_model_gpu():
     err = ((a - b).norm() / b.norm()).item()
     cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
     assert torch.isfinite(a).all() and err < 0.25 and cos > 0.97, (err, cos)
-    out16.float().sum().backward()
+    loss = out16.float().sum()
+    if os.environ.get("BEVR_TRACE_BACKWARD") == "1":
+        # localisation aid: with HIP_LAUNCH_BLOCKING=1 the last node named on stderr before a GPU fault
+        # is the one whose kernel faulted
+        import sys
+        seen, todo = set(), [loss.grad_fn]
+        while todo:
+            fn = todo.pop()
+            if fn is None or fn in seen:
+                continue
+            seen.add(fn)
+            fn.register_prehook(lambda g, _n=fn.name(): (sys.stderr.write(f"[bwd] {_n}\n"), sys.stderr.flush(), None)[2])
+            todo.extend(f for f, _ in fn.next_functions)
+    loss.backward()
     torch.cuda.synchronize()
     gq = m16.bev_embedding.weight.grad
     assert gq is not None and torch.isfinite(gq).all() and gq.abs().sum() > 0

@@ -381,11 +381,11 @@ def main():
         dom = max(attn, key=lambda k: attn[k]["ms"]) if attn else None
         roof = None
         # HBM bytes per launch: measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very command (separate
-        # passes, gfx950 correction applied) by tools/measure_traffic.sh, which writes profiles/r04_traffic.json together
+        # passes, gfx950 correction applied) by tools/measure_traffic.sh, which writes profiles/r05_traffic.json together
         # with the kernel sources' sha; only attached when that file was measured at this batch / BEV side / precision
         # AND on these very kernel sources (a stale file is not reported as measured traffic: ADVICE r02)
-        traffic_db, traffic_note = {}, "no profiles/r04_traffic.json for this batch / BEV side / precision"
-        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
+        traffic_db, traffic_note = {}, "no profiles/r05_traffic.json for this batch / BEV side / precision"
+        tpath = os.path.join(ROOT, "profiles", "r05_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as fh:
                 tj = json.load(fh)
@@ -393,7 +393,7 @@ def main():
                 if tj.get("csrc_sha") == csrc_sha():
                     traffic_db, traffic_note = tj["kernels"], f"measured at csrc_sha {tj.get('csrc_sha')}"
                 else:
-                    traffic_note = (f"profiles/r04_traffic.json was measured at csrc_sha {tj.get('csrc_sha')}, the kernels "
+                    traffic_note = (f"profiles/r05_traffic.json was measured at csrc_sha {tj.get('csrc_sha')}, the kernels "
                                     f"are at {csrc_sha()}: not attached")
         if dom:
             rec = attn[dom]

@@ -725,7 +725,7 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
         raise ValueError("rpe_table height must be 2S-1")
     tap = bool(tap_source) and split < N
     if tap and (kv_source is None or not tap_supported(precision, groups) or 16 * ((S + 15) // 16) > 448):
-        raise ValueError("tap_source needs kv_source, groups == 1, the bf16 operand mode and S <= 448")
+        raise ValueError("tap_source needs kv_source, groups == 1, a 16-bit operand mode and S <= 448")
     geom = AttnGeom(n_prob=Bp, q_div=views, heads=heads, groups=groups, S=S, N=split if tap else N, Wt=Wt, precision=precision)
     f32_layout = precision in (_lib.PREC_F32, _lib.PREC_BF16X3)
     if not tap and split < N and (geom.Sp > 480 or (f32_layout and geom.Sp > 224) or (N - split) > 8 * 100 * 1024):
@@ -780,6 +780,14 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
 # --------------------------------------------------------------------------------------------------
 TAP_R, TAP_C, TAP_N, TAP_SLOTS = 4, 3, 12, 16     # csrc/attn_tap.h: feature rows 0..3 x columns 0..2, 16 operand slots
 TAP_HEADROOM = 64.0                               # binades between the static softmax reference and the logits' upper bound
+TAP_HEADROOM_F16 = 8.0                            # fp16 operands: the weights 2^(S - mref) are rounded to fp16 (largest value
+                                                  # 2^15.9; include/bevrender_hip.h: headroom <= 8).  Weights more than ~32
+                                                  # binades under the bound flush to zero; a row that loses ALL of them is
+                                                  # flagged and recomputed with an online maximum (the EXACT pass)
+
+
+def tap_headroom(precision: int) -> float:
+    return TAP_HEADROOM_F16 if precision == _lib.PREC_F16 else TAP_HEADROOM
 LN2 = 0.6931471805599453
 
 
@@ -829,7 +837,7 @@ class _TapAttn(torch.autograd.Function):
         # weights up to their 16-bit rounding) minus the headroom -- no weight can overflow, nothing is tracked in the loop
         tmax = Ttc.amax(-1).amax(-1).clamp_min(0.0)       # two stages: see _AttnCore.forward
         ub = 1.01 * (G16[..., :TAP_N].float().amax(-1).clamp_min(0.0) + tmax[None, :, None]) + 0.01
-        mref = (-_set_offset(G16, TAP_HEADROOM - ub)).contiguous()
+        mref = (-_set_offset(G16, tap_headroom(geom.precision) - ub)).contiguous()
         # zeros: the kernels work in 16-row blocks and never touch the rows past the last block of a column
         R = torch.zeros(P, h, Mp, TAP_SLOTS, device=dev, dtype=torch.float32)
         flags = torch.zeros(P * h, geom.S, device=dev, dtype=torch.int32)
@@ -856,6 +864,19 @@ class _TapAttn(torch.autograd.Function):
         d = geom.desc()
         valid = (torch.arange(Mp, device=dev) % geom.Sp) < geom.S
         H16 = torch.zeros(P, h, Mp, TAP_SLOTS, device=dev, dtype=ed)
+        sdo = None
+        if ed == torch.float16:
+            # fp16 has 5 exponent bits and the reference trains without a loss scaler: the cotangents of a mean-type loss
+            # (~1e-7 per element) would fall into fp16's subnormals as the H operand.  Every output is linear in
+            # (dRn, dLSE): both are brought to ~2^8 with a power of two (exact) and the gradients scaled back.  No sync.
+            big = torch.zeros((), device=dev)
+            if dRn is not None:
+                big = torch.maximum(big, dRn.abs().max())
+            if dLSE is not None:
+                big = torch.maximum(big, dLSE.abs().max())
+            sdo = torch.exp2(torch.floor(8.0 - torch.log2(big.clamp_min(1e-30))))
+            dRn = None if dRn is None else dRn * sdo
+            dLSE = None if dLSE is None else dLSE * sdo
         if dRn is not None:
             H16[..., :TAP_N] = dRn * LN2
         # delta from the values the kernel contracts (the rounded H): dS = P (dP - delta) then cancels where P -> 1
@@ -873,12 +894,17 @@ class _TapAttn(torch.autograd.Function):
         _lib.check(KERNEL_TIMER.run("bevr_attn_tap_bwd_k", _attn_flops(geom, 4), L.bevr_attn_tap_bwd_k, C.byref(d), _ptr(Gq),
                                     _ptr(H16), _ptr(ws), _ptr(Ttc), *[_ptr(t) for t in dk], _stream(), tag=_call_tag(geom)), "bevr_attn_tap_bwd_k")
         da, db, dy, dx = (t[:, :geom.N] for t in dk)
-        return dG[..., :TAP_N] * valid[:, None], da, db, dy, dx, dT, None
+        dGo = dG[..., :TAP_N] * valid[:, None]
+        if sdo is not None:
+            inv = 1.0 / sdo
+            dGo, da, db, dy, dx, dT = dGo * inv, da * inv, db * inv, dy * inv, dx * inv, dT * inv
+        return dGo, da, db, dy, dx, dT, None
 
 
 def tap_supported(precision: int, groups: int) -> bool:
-    """BEVR_TAP=0 keeps the pinned keys on the cell kernels."""
-    return precision == _lib.PREC_BF16 and groups == 1 and os.environ.get("BEVR_TAP", "1") != "0"
+    """The 16-bit operand modes (fp16 since round 5: headroom 8 and a power-of-two scale on the cotangents, see
+    _TapAttn); BEVR_TAP=0 keeps the pinned keys on the cell kernels."""
+    return precision in (_lib.PREC_BF16, _lib.PREC_F16) and groups == 1 and os.environ.get("BEVR_TAP", "1") != "0"
 
 
 def kv_source_supported(C: int, heads: int, groups: int, precision: int) -> bool:

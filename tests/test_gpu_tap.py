@@ -144,6 +144,32 @@ def test_attention_core_with_tap_source_matches_the_oracle(cfg):
         assert e < 3e-2, f"grad {n}: rel err {e:.3e}"
 
 
+@pytest.mark.parametrize("cfg", TAP_CFGS[:3])
+def test_attention_core_with_tap_source_in_fp16_matches_the_oracle(cfg):
+    """BASELINE config 5's operand type on the tap route (round 5: headroom 8, cotangents scaled by a power of two): the
+    same comparison at the fp16 limits of tests/test_gpu_fullsize.py, with a mean-type loss (cotangents ~1e-5: fp16
+    subnormals without the scale)."""
+    B, V, C, h, S, D, Hi, Wi, n_pin = cfg
+    ins = _tap_problem(B, V, C, h, S, D, Hi, Wi, n_pin, seed=sum(cfg) + 1)
+    split = ins[-1]
+    cpu = [t.clone().double().requires_grad_(True) for t in ins[:-1]]
+    want = _oracle_chain(*cpu, h, V)
+    cot = torch.randn(want.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64) * 1e-5
+    want.backward(cot)
+    gpu = [t.clone().to(DEV).requires_grad_(True) for t in ins[:-1]]
+    query, feat, Wkv, bkv, pos, table = gpu
+    assert ops.tap_supported(_lib.PREC_F16, 1)
+    got = ops.attention_core(query, None, None, pos, table, heads=h, groups=1, views=V, precision=_lib.PREC_F16,
+                             kv_source=(feat, Wkv, bkv), cell_split=split, tap_source=True)
+    got.backward(cot.float().to(DEV))
+    torch.cuda.synchronize()
+    e = rel_err(got.detach().double().cpu(), want.detach())
+    assert e < 2.5e-3, f"out: rel err {e:.3e}"
+    for n, a, b in zip(["query", "feat", "Wkv", "bkv", "pos", "table"], gpu, cpu):
+        e = rel_err(a.grad.double().cpu(), b.grad)
+        assert e < 5e-3, f"grad {n}: rel err {e:.3e}"
+
+
 def test_tap_and_cell_kernels_agree_on_the_same_keys():
     """the same call with the pinned keys on the tap kernels and on the cell kernels (K, V formed): two routes to one
     softmax, both in bf16 operands."""

@@ -78,14 +78,14 @@ def test_bf16_staging_full_model_gpu():
     if os.environ.get("BEVR_TRACE_BACKWARD") == "1":
         # localisation aid: with HIP_LAUNCH_BLOCKING=1 the last node named on stderr before a GPU fault
         # is the one whose kernel faulted
-        import sys
         seen, todo = set(), [loss.grad_fn]
         while todo:
             fn = todo.pop()
             if fn is None or fn in seen:
                 continue
             seen.add(fn)
-            fn.register_prehook(lambda g, _n=fn.name(): (sys.stderr.write(f"[bwd] {_n}\n"), sys.stderr.flush(), None)[2])
+            # file descriptor 2 itself: sys.stderr is pytest's capture object (--capture=sys) and dies with the process
+            fn.register_prehook(lambda g, _n=fn.name(): (os.write(2, f"[bwd] {_n}\n".encode()), None)[1])
             todo.extend(f for f, _ in fn.next_functions)
     loss.backward()
     torch.cuda.synchronize()

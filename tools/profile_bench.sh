@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the bench command; summary -> gpurun_out/<tag>_kernel_stats.csv (copy to profiles/)
 # Run on the GPU box from the repo root:  bash tools/profile_bench.sh r03_a [extra bench args]
-TAG=${1:-r04}; shift
+TAG=${1:-r05}; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=/tmp/bevr_prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp

@@ -470,15 +470,14 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       };
       // one flush per (slab, column): this wave saw every key of the column's run
       auto flush_dq = [&]() {
-        if (live) {
-          float* row = dQ + ((size_t)ph * Mp + (size_t)jcur * d.Sp + qrow) * 32;
+        // dq[r]: query i0 + crow(r, hi), channel lq (dq_product): a wave instruction adds two 128-byte rows
+        float* base = dQ + ((size_t)ph * Mp + (size_t)jcur * d.Sp + i0) * 32 + lq;
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd(row + 8 * g4 + 4 * hi + k, dq_scale * dq[4 * g4 + k]);
+        for (int r = 0; r < 16; ++r) {
+          const int qr = crow(r, hi);
+          if (qr < SQROWS && i0 + qr < d.S) atomicAdd(base + (size_t)qr * 32, dq_scale * dq[r]);
+          dq[r] = 0.f;
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
       };
 
       // One emission -- both 32-key halves, one after the other -- against this wave's 31 queries.  The key-row loop of a
@@ -530,7 +529,18 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           const char* p = bb + (h * 32 + 4 * hi + (i16 >> 2)) * SKROW + chalf * 32 + 8 * (i16 & 3);
           ktf.v[0] = lds_tr8(p, 8 * SKROW);
           ktf.v[1] = lds_tr8(p + 16 * SKROW, 8 * SKROW);
-          dq = mma_acc_b(ktf, s[h], dq);
+          // dQ[query][channel] += dS[query][key] K[key][channel]: the accumulator tile of dS^T (key rows in registers, query
+          // on the lane) is the A operand as it stands -- lane (query, hi) holds the keys crow(8 s + j, hi) of k-step s,
+          // the same key order as ktf's -- and the product comes out with the CHANNEL on the lane: the flush below adds
+          // 128 contiguous bytes per query row (with the query on the lane, as the first version had it, every lane of an
+          // atomic instruction hit its own cache line: 85 GB of atomic write traffic per launch against ~23 GB of payload)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            u32x4 w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = Half<PREC>::pack2(s[h][8 * ks + 2 * k], s[h][8 * ks + 2 * k + 1]);
+            dq = Half<PREC>::mfma(__builtin_bit_cast(bf16x8, w), ktf.v[ks], dq);
+          }
         };
 #pragma unroll
         for (int h = 0; h < 2; ++h) {

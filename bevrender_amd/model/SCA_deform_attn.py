@@ -179,13 +179,15 @@ class SCADeformableAttention(nn.Module):
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
                                    precision=self.precision, kv_source=(feat, Wkv, bkv), cell_split=cell_split,
                                    tap_source=bool(split_is_pinned) and cell_split is not None and self._pinned_keys_tap(S, Hi, Wi),
-                                   attn_drop=drop)
+                                   attn_drop=drop, concat_views=True)
         else:
             xs = ops.sample_features(xf, pos, g)                                     # (B*V, N, C)
             kv = F.linear(xs, Wkv, bkv)
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=g, views=V,
-                                   precision=self.precision, kv=kv, cell_split=cell_split, attn_drop=drop)   # (B*V, S*S, C)
-        o = o.reshape(B, V, S * S, C).permute(0, 2, 1, 3).reshape(B, S * S, V * C)
+                                   precision=self.precision, kv=kv, cell_split=cell_split, attn_drop=drop,
+                                   concat_views=True)
+        # o: (B, S*S, V*C), the views side by side as proj_out contracts them (reference :415-420), written by the
+        # attention's unpacking in one pass: no (B, V, M, C) -> (B, M, V C) permute copy in between
         out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
         out = F.dropout(out, self.proj_drop_rate, self.training)                      # reference :420 (proj_drop)
         return out.permute(0, 2, 1).reshape(B, C, S, S), wandb_log_dict

@@ -112,6 +112,17 @@ def unpack_out(O: torch.Tensor, S: int, c: int) -> torch.Tensor:
     return o.permute(0, 3, 2, 1, 4).reshape(Bp, S * S, h * c)
 
 
+def unpack_out_views(O: torch.Tensor, S: int, c: int, views: int) -> torch.Tensor:
+    """(B * views, h, Mp, 32) -> (B, S*S, views * h * c): the views of a sample side by side in the channel axis, view-major
+    -- the layout `proj_out` of SCA contracts (reference model/SCA_deform_attn.py:415-420: the per-view outputs
+    concatenated along channels, then a 1x1 convolution V C -> C) -- in ONE copy out of the packed layout (unpack_out
+    followed by the reference's reshape / permute of the views was two: 2 x 491 MB per call at the benchmark)."""
+    BV, h, Mp, _ = O.shape
+    Sp = Mp // S
+    o = O.reshape(BV // views, views, h, S, Sp, HEAD_DIM)[:, :, :, :, :S, :c]        # (B, v, h, j, i, c)
+    return o.permute(0, 4, 3, 1, 2, 5).reshape(BV // views, S * S, views * h * c)
+
+
 def key_coords(pos: torch.Tensor, S: int, Wt: int, Np: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """pos (P, N, 2) in (y, x), [-1, 1] units -> table coordinates a (rows), b (cols), padded to Np.
     ty = i + a, tx = j*rx + b reproduces grid_sample(align_corners=True) of (q_grid - pos)/2
@@ -667,7 +678,7 @@ class _AttnCore(torch.autograd.Function):
 def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Optional[torch.Tensor], pos: torch.Tensor,
                    rpe_table: torch.Tensor, *, heads: int, groups: int, views: int, precision: int,
                    kv: Optional[torch.Tensor] = None, cell_split: Optional[int] = None, kv_source=None,
-                   tap_source=None, attn_drop=None) -> torch.Tensor:
+                   tap_source=None, attn_drop=None, concat_views: bool = False) -> torch.Tensor:
     """Fused attention of the BEV query against sampled keys.
 
     query (B, C, S, S) layer-normed BEV query (used raw as Q); kproj, vproj (B*views, N, C) projected
@@ -688,7 +699,9 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     probability 1 - p (p rounded to 1/65536) and scaled by 1 / (1 - p); the mask is the function dropout_keep_mask of
     (seed, problem-head, query, key) that the forward and backward kernels share.  Every key then runs on the region
     kernels (cell_split / tap_source are ignored).
-    Returns (B*views, S*S, C): per view softmax(QK^T c^-0.5 + bias) V, rows in i*S + j order.
+    Returns (B*views, S*S, C): per view softmax(QK^T c^-0.5 + bias) V, rows in i*S + j order -- or, with
+    concat_views=True, (B, S*S, views*C): the views side by side in the channel axis (unpack_out_views: what SCA's
+    proj_out contracts, written in one pass).
     Replaces model/SCA_deform_attn.py:304-413 / model/TSA_deform_attn.py:220-333.
     """
     B, Cc, S, _ = query.shape
@@ -742,7 +755,7 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
             O, _ = _AttnCore.apply(Qp, None, a, b, Tt, geom, split, feat, pos.float(), Wkv, bkv, drop)
         else:
             O, _ = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split, None, None, None, None, drop)
-        return unpack_out(O, S, c)
+        return unpack_out_views(O, S, c, views) if concat_views else unpack_out(O, S, c)
 
     # ---- keys [0, split): region kernels; keys [split, N): tap kernels; one softmax, merged through (O, LSE) ----
     V = views
@@ -769,10 +782,10 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     bv = F.pad(bkv[Cc:].float().reshape(1, heads, 1, c), (0, pad_c))
     O_c = torch.matmul(Rn, Vp) + bv
     if O_r is None:
-        return unpack_out(O_c, S, c)
+        return unpack_out_views(O_c, S, c, views) if concat_views else unpack_out(O_c, S, c)
     LSE_t = torch.logaddexp2(LSE_r, LSE_c)
     O = torch.exp2(LSE_r - LSE_t)[..., None] * O_r + torch.exp2(LSE_c - LSE_t)[..., None] * O_c
-    return unpack_out(O, S, c)
+    return unpack_out_views(O, S, c, views) if concat_views else unpack_out(O, S, c)
 
 
 # --------------------------------------------------------------------------------------------------

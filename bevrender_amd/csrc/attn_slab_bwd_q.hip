@@ -424,7 +424,6 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       const int qrow = i0 + lq;
       const bool live = lq < SQROWS && qrow < d.S;
       const int rowoff4 = (i0 + lq) * 4;
-      const int nq = min(SQROWS, d.S - i0);     // live queries of this row block; lane nq is the slot of the last one's lower tap
       const char* Qh = Q + ((size_t)(qb * d.heads + hd) * Mp) * 64;
       const char* dOh = dO + ((size_t)ph * Mp) * 64;
       const unsigned cells_off = (unsigned)(reinterpret_cast<char*>(cells) - lds);
@@ -489,7 +488,7 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
       // second half are issued before the first half's loop, the first half's dQ product before the second half's loop.
       // CLAMP: the row index is clamped into the window.  jn >= 0: the column's last emission -- once the products that
       // read Q and dO are issued, the rows of column jn are requested INTO the same registers.
-      auto process = [&](const char* bb, int jn, unsigned hmask, auto clamp_tag) {
+      auto process = [&](const char* bb, int jn, auto clamp_tag) {
         constexpr bool CLAMP = decltype(clamp_tag)::value;
         const SlabCK* pk0 = reinterpret_cast<const SlabCK*>(bb + L::OFF_CK);
         f32x16 s[2], dp[2];
@@ -503,7 +502,6 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          if (!((hmask >> h) & 1u)) continue;
           Frag<PREC> kf, vkf;
           kf.load(bb + (h * 32 + lq) * SKROW, hi);
           s[h] = mma_frag(kf, qf, s[h]);          // S^T - LSE
@@ -547,12 +545,6 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const SlabCK* pk = pk0 + h * 32;
-          // lanes past the row block's last table row (a ragged last block: S = 200 leaves 14 queries to the seventh wave)
-          // sit the loop out: an LDS instruction costs by its active lanes, and that wave was the one the barrier waited
-          // for.  Their S rows keep stale values: rows of queries that do not exist, never flushed.  A half without a
-          // live key (the tail of a column's run) is skipped altogether.
-          if (!((hmask >> h) & 1u)) continue;
-          if (lq <= nq) {
           // chain c walks the key rows c * 8 + 0 .. 7 of the accumulator tile
           SlabCK e0[2], e1[2];
           int o0[2];
@@ -618,7 +610,6 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
               e0[c] = e1[c]; e1[c] = e2[c]; ta[c] = na[c]; tb[c] = nb[c]; o0[c] = o1[c];
             }
           }
-          }
           // the half's dQ product: issued here, it runs under the other half's loop (h = 0) or the barrier wait (h = 1)
           dq_product(h);
           __builtin_amdgcn_sched_barrier(0);
@@ -647,8 +638,8 @@ __global__ __launch_bounds__(STHREADS, 1) void attn_slab_bwd_q_kernel(
           const unsigned hb = flags >> 8;          // bits 0, 1: the halves with a live key; bits 2, 3: with a far one
           if (hb & 3u) {
             const int jn = (flags & SF_LAST) ? (int)(jword >> 16) - 1 : -1;
-            if (hb & 12u) process(bb, jn, hb & 3u, std::true_type{});
-            else process(bb, jn, hb & 3u, std::false_type{});
+            if (hb & 12u) process(bb, jn, std::true_type{});
+            else process(bb, jn, std::false_type{});
           }
           if (flags & SF_LAST) flush_dq();
         }

@@ -31,7 +31,9 @@ __device__ __forceinline__ f32x4 ld4(const bf16_bits* p) {
 
 struct KvGeom {
   int nb, Hi, Wi, C, N, Np, heads, c;
-  long long pos_pstride;   // keys between two problems' positions (the caller's array may hold more keys than N)
+  long long pos_pstride;   // keys between two position blocks (the caller's array may hold more keys than N)
+  int groups;              // channel groups: group gi's C / groups channels are sampled at position block b * groups + gi
+                           // (model/SCA_deform_attn.py:290-301: x.reshape(B g, C / g, Hi, Wi) against pos (B g, ...))
 };
 
 template <int PREC, typename T>
@@ -53,7 +55,8 @@ __global__ __launch_bounds__(KVP_THREADS) void kv_project_kernel(KvGeom g, const
     const int key = it / c4n, c4 = it - key * c4n;
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
     if (n0 + key < g.N) {
-      const f32x2 p = *reinterpret_cast<const f32x2*>(pos + ((size_t)b * g.pos_pstride + n0 + key) * 2);
+      const int gi = (c4 * 4) / (C / g.groups);
+      const f32x2 p = *reinterpret_cast<const f32x2*>(pos + (((size_t)b * g.groups + gi) * g.pos_pstride + n0 + key) * 2);
       const float ix = (p[1] + 1.0f) * 0.5f * (float)(g.Wi - 1), iy = (p[0] + 1.0f) * 0.5f * (float)(g.Hi - 1);
       float x0f = floorf(ix), y0f = floorf(iy);
       const float fx = ix - x0f, fy = iy - y0f;
@@ -168,16 +171,17 @@ int launch(const KvGeom& g, const T* feat, const float* pos, const void* Wkv, co
 
 extern "C" int bevr_kv_project(const void* feat, int feat_bf16, const float* pos, long long pos_pstride, const void* Wkv,
                                const float* bkv, int nb, int Hi, int Wi, int C, int N, int Np, int heads, int c,
-                               int precision, void* Kr, void* Vr, void* Kt, void* Vt, float* vnorm2_max, void* stream) {
+                               int precision, void* Kr, void* Vr, void* Kt, void* Vt, float* vnorm2_max, int groups,
+                               void* stream) {
   if (!feat || !pos || !Wkv || !Kr || !Vr || !Vt) return BEVR_E_NULL;
   if (nb <= 0 || Hi < 2 || Wi < 2 || N <= 0 || Np < N || Np % KVP_KEYS || heads <= 0 || c <= 0 || c > 32 ||
-      C != heads * c || (C & 15) || C > 256 || pos_pstride < N)
+      C != heads * c || (C & 15) || C > 256 || pos_pstride < N || groups <= 0 || C % groups || ((C / groups) & 3))
     return BEVR_E_SHAPE;
   if (!is16(precision)) return BEVR_E_PRECISION;   // the f32-layout modes keep the unfused chain
   if (!bevr_aligned16(feat) || !bevr_aligned16(Wkv) || !bevr_aligned16(Kr) || !bevr_aligned16(Vr) || !bevr_aligned16(Vt) ||
       (Kt && !bevr_aligned16(Kt)) || (reinterpret_cast<uintptr_t>(pos) & 7))
     return BEVR_E_ALIGN;
-  const KvGeom g{nb, Hi, Wi, C, N, Np, heads, c, pos_pstride};
+  const KvGeom g{nb, Hi, Wi, C, N, Np, heads, c, pos_pstride, groups};
   hipStream_t st = (hipStream_t)stream;
   if (precision == BEVR_PREC_BF16)
     return feat_bf16 ? launch<BEVR_PREC_BF16>(g, static_cast<const bf16_bits*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, st)

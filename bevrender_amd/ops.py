@@ -468,7 +468,7 @@ class _AttnCore(torch.autograd.Function):
                 _lib.check(KERNEL_TIMER.run(
                     "bevr_kv_project", 0.0, L.bevr_kv_project, _ptr(feat), int(feat.dtype == torch.bfloat16),
                     C.c_void_p(spos.data_ptr() + sg.n0 * 8), N, _ptr(W_e), _ptr(b_f), nb, Hi, Wi, Cc, g.N, g.Np, g.heads, c,
-                    g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _ptr(vn2) if need_bwd else None, _stream(),
+                    g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _ptr(vn2) if need_bwd else None, g.groups, _stream(),
                     nbytes=float(feat.numel() * feat.element_size() + 8 * nb * g.N + (4 if need_bwd else 3) * Ke.numel() * 2)),
                     "bevr_kv_project")
             else:
@@ -665,6 +665,21 @@ class _AttnCore(torch.autograd.Function):
         # adjoint of the fused K | V source in its unfused form: the projection's GEMMs on the float samples (recomputed:
         # the forward never wrote them) and the sampler's scatter
         feat, spos, Wkv = src[0], src[1], src[2]
+        G = geom.groups
+        if G > 1:
+            # group gi's channels sampled at group gi's positions: the map as B' G images of C / G channels (a copy of the
+            # feature map: small next to the rows), the rows back to (B', N, C)
+            nb, Hi, Wi, Cc = feat.shape
+            fg = feat.reshape(nb, Hi, Wi, G, Cc // G).permute(0, 3, 1, 2, 4).reshape(nb * G, Hi, Wi, Cc // G).contiguous()
+            xs = _Sample.sample(fg, spos).reshape(nb, G, -1, Cc // G).permute(0, 2, 1, 3).reshape(nb, -1, Cc)
+            d2 = dkv.reshape(-1, dkv.shape[-1])
+            dW = torch.bmm(dkv.transpose(1, 2), xs).sum(0) if ctx.needs_input_grad[9] else None
+            dbias = d2.sum(0) if ctx.has_bias and ctx.needs_input_grad[10] else None
+            dxs = (d2 @ Wkv.float()).reshape(nb, -1, G, Cc // G).permute(0, 2, 1, 3).reshape(nb * G, -1, Cc // G).contiguous()
+            del xs
+            dfg, dspos = _Sample.scatter(fg, spos, dxs, ctx.needs_input_grad[7])
+            dfeat = None if dfg is None else dfg.reshape(nb, G, Hi, Wi, Cc // G).permute(0, 2, 3, 1, 4).reshape(feat.shape)
+            return dQ, None, da, db, dT, None, None, dfeat, dspos, dW, dbias, None
         xs = _Sample.sample(feat, spos)                                              # (B', N, C) float
         d2 = dkv.reshape(-1, dkv.shape[-1])
         # the weight gradient as one GEMM per problem, summed: rocBLAS runs the single (2C x B'N) @ (B'N x C) product with
@@ -691,8 +706,8 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     segment).  Any split gives the same result; it only decides the speed.
     kv_source = (feat, Wkv, bkv) instead of kproj / vproj / kv: feat (B*views, Hi, Wi, C) the channels-last feature map
     (float or bf16) the keys are sampled from AT `pos`, Wkv (2C, C) / bkv (2C,) the proj_k | proj_v weights: sampling,
-    projection and operand packing run as one kernel (csrc/kvproj.hip; groups == 1, 16-bit operand modes -- see
-    kv_source_supported).
+    projection and operand packing run as one kernel (csrc/kvproj.hip; 16-bit operand modes; with channel groups pos is
+    (B*views*groups, N, 2) and group gi's channels are sampled at its own positions -- see kv_source_supported).
     tap_source = True (with kv_source and cell_split): the keys [cell_split, N) all sample inside the top-left 4 x 3
     pixels of `feat` (the caller's contract: the projector-pinned keys, tap_supported) and go through the TAP kernels
     (csrc/attn_tap.h): their K and V are never formed -- the logits come from G = Q Kpix^T (12 pixels), the output from
@@ -719,10 +734,10 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
             raise ValueError("pass kv_source alone")
         feat, Wkv, bkv = kv_source
         if not kv_source_supported(Cc, heads, groups, precision):
-            raise ValueError("kv_source needs groups == 1, a 16-bit operand mode and C % 16 == 0")
-        Bp, N = pos.shape[0], pos.shape[1]
-        if feat.shape[0] != Bp or feat.shape[-1] != Cc or tuple(Wkv.shape) != (2 * Cc, Cc):
-            raise ValueError("kv_source shapes: feat (B*views, Hi, Wi, C), Wkv (2C, C)")
+            raise ValueError("kv_source needs a 16-bit operand mode, C % 16 == 0 and (C / groups) % 4 == 0")
+        Bp, N = feat.shape[0], pos.shape[1]
+        if pos.shape[0] != Bp * groups or feat.shape[-1] != Cc or tuple(Wkv.shape) != (2 * Cc, Cc):
+            raise ValueError("kv_source shapes: feat (B*views, Hi, Wi, C), pos (B*views*groups, N, 2), Wkv (2C, C)")
     else:
         if kv is None:
             kv = torch.cat((kproj, vproj), -1)
@@ -926,8 +941,9 @@ def kv_source_supported(C: int, heads: int, groups: int, precision: int) -> bool
     """Can the K | V operands come from the fused sample -> project -> pack kernel (csrc/kvproj.hip)?  BEVR_FUSED_KV=0
     turns it off (the unfused chain sample -> rocBLAS -> bevr_pack_kv is then used; same results to the operands'
     rounding)."""
-    return (groups == 1 and precision in (_lib.PREC_BF16, _lib.PREC_F16) and C % 16 == 0 and C <= 256
-            and C % heads == 0 and C // heads <= 32 and os.environ.get("BEVR_FUSED_KV", "1") != "0")
+    return (groups >= 1 and C % groups == 0 and (C // groups) % 4 == 0 and precision in (_lib.PREC_BF16, _lib.PREC_F16)
+            and C % 16 == 0 and C <= 256 and C % heads == 0 and C // heads <= 32
+            and os.environ.get("BEVR_FUSED_KV", "1") != "0")
 
 
 class _Sample(torch.autograd.Function):

@@ -48,7 +48,8 @@ extern "C" {
  *    changed. */
 /* 5: new entry points bevr_attn_slab_ws_bytes / _slab_prep / _slab_bwd_q (the query-side backward cut along the rpe
  *    table: a workgroup owns a slab of table columns); bevr_attn_tap_bwd_k's table operand is declared as what it always
- *    was (the plain packed table, not the pair table); nothing else changed. */
+ *    was (the plain packed table, not the pair table); bevr_kv_project takes the channel-group count (before `stream`);
+ *    nothing else changed. */
 #define BEVR_ABI_VERSION 5
 
 enum {
@@ -423,9 +424,13 @@ int bevr_layernorm_bwd(const float* x, const float* gamma, const float* dy, cons
  * K | V operands straight from the feature map (16-bit operand modes): bilinear sampling at `pos` -> proj_k | proj_v
  * as one 1x1 GEMM on the matrix cores -> the packed layouts below, in one pass; the sampled features and the projected
  * rows never reach HBM.  Replaces bevr_sample_fwd -> GEMM -> bevr_pack_kv, i.e. F.grid_sample + proj_k / proj_v + the
- * per-head reshapes of model/SCA_deform_attn.py:290-321, model/TSA_deform_attn.py:210-236 (channel groups == 1).
+ * per-head reshapes of model/SCA_deform_attn.py:290-321, model/TSA_deform_attn.py:210-236.
  *   feat [nb][Hi][Wi][C]  float, or bf16 bits if feat_bf16 (channels-last)
- *   pos  (y, x) of key n of problem b at pos[(b * pos_pstride + n) * 2]   (a key segment: pass pos + 2 n0)
+ *   groups: channel groups (ABI 5; the reference's n_groups): the C / groups channels of group gi are sampled at group gi's
+ *        positions -- x.reshape(B g, C / g, Hi, Wi) against pos (B g, N, 2), model/SCA_deform_attn.py:290-301 -- and the
+ *        projection then mixes all C channels as before.  C % groups == 0, (C / groups) % 4 == 0.
+ *   pos  (y, x) of key n of problem b, group gi at pos[((b * groups + gi) * pos_pstride + n) * 2]   (a key segment:
+ *        pass pos + 2 n0)
  *   Wkv  [2C][C] E (E = bf16 / fp16 per `precision`: the caller rounds the float weights once), rows 0..C-1 = proj_k
  *   bkv  [2C] float or NULL
  *   outputs as bevr_pack_kv: Kr, Vr [nb][heads][Np][32] E, Kt (or NULL), Vt [nb][heads][32][Np] E; keys N..Np-1 zero.
@@ -436,7 +441,7 @@ int bevr_layernorm_bwd(const float* x, const float* gamma, const float* dy, cons
  * ---------------------------------------------------------------------------------------------- */
 int bevr_kv_project(const void* feat, int feat_bf16, const float* pos, long long pos_pstride, const void* Wkv,
                     const float* bkv, int nb, int Hi, int Wi, int C, int N, int Np, int heads, int c, int precision,
-                    void* Kr, void* Vr, void* Kt, void* Vt, float* vnorm2_max, void* stream);
+                    void* Kr, void* Vr, void* Kt, void* Vt, float* vnorm2_max, int groups, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Key positions from the offset heads' outputs, in the attention's key order, and the adjoint (one launch each).

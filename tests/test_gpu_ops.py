@@ -670,7 +670,7 @@ def test_kv_project_equals_sample_gemm_pack(shape, feat_bf16, prec):
     We = W.to(ed).contiguous()
     vn2 = torch.zeros(1, device=DEV)
     rc = _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), C.c_void_p(pos.data_ptr() + n0 * 8), N, p(We), p(bias), Bp, Hi,
-                                    Wi, Cc, Ns, Np, h, c, prec, p(Kr), p(Vr), p(Kt), p(Vt), p(vn2), st)
+                                    Wi, Cc, Ns, Np, h, c, prec, p(Kr), p(Vr), p(Kt), p(Vt), p(vn2), 1, st)
     assert rc == 0
     xs = ops._Sample.sample(feat, pos)[:, n0:]                              # float samples, the unfused kernel
     kv = (xs.to(ed).double() @ We.double().t() + bias.double()).float()     # products of E values, exact accumulation
@@ -692,11 +692,49 @@ def test_kv_project_equals_sample_gemm_pack(shape, feat_bf16, prec):
     # no transposed K requested (forward-only call)
     Kr2, Vr2, Vt2 = mk(Bp, h, Np, 32), mk(Bp, h, Np, 32), mk(Bp, h, 32, Np)
     assert _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), C.c_void_p(pos.data_ptr() + n0 * 8), N, p(We), p(bias), Bp,
-                                      Hi, Wi, Cc, Ns, Np, h, c, prec, p(Kr2), p(Vr2), None, p(Vt2), None, st) == 0
+                                      Hi, Wi, Cc, Ns, Np, h, c, prec, p(Kr2), p(Vr2), None, p(Vt2), None, 1, st) == 0
     assert torch.equal(Kr2, Kr) and torch.equal(Vt2, Vt)
     # argument contract: f32-layout modes are refused
     assert _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), p(pos), N, p(We), p(bias), Bp, Hi, Wi, Cc, Ns, Np, h, c,
-                                      _lib.PREC_F32, p(Kr), p(Vr), None, p(Vt), None, st) == -3
+                                      _lib.PREC_F32, p(Kr), p(Vr), None, p(Vt), None, 1, st) == -3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups", [2, 4])
+def test_fused_kv_source_with_channel_groups_matches_the_unfused_chain(groups):
+    """n_groups > 1 on the fused path (reference model/SCA_deform_attn.py:219-255, 290-301 with g): group
+    gi's channels are sampled at group gi's positions inside bevr_kv_project; forward and every gradient against
+    sample_features -> F.linear -> attention_core(kv=...), bf16 operands."""
+    B, V, Cc, h, S, D, Hi, Wi = 1, 2, 64, 4, 10, 3, 12, 20
+    N = (S // 2) * S * D
+    gen = torch.Generator().manual_seed(70 + groups)
+    query = torch.randn(B, Cc, S, S, generator=gen)
+    feat = torch.randn(B * V, Hi, Wi, Cc, generator=gen)
+    pos = torch.rand(B * V * groups, N, 2, generator=gen) * 2.2 - 1.1
+    W = torch.randn(2 * Cc, Cc, generator=gen) / Cc ** 0.5
+    bias = torch.randn(2 * Cc, generator=gen) * 0.1
+    table = torch.randn(h, 2 * S - 1, 2 * S * D - 1, generator=gen) * 0.3
+    cot = torch.randn(B * V, S * S, Cc, generator=gen).to(DEV)
+    assert ops.kv_source_supported(Cc, h, groups, _lib.PREC_BF16)
+    res = []
+    for fused in (True, False):
+        ins = [t.clone().to(DEV).requires_grad_(True) for t in (query, feat, pos, W, bias, table)]
+        q, f, p_, w, b_, t = ins
+        if fused:
+            out = ops.attention_core(q, None, None, p_, t, heads=h, groups=groups, views=V, precision=_lib.PREC_BF16,
+                                     kv_source=(f, w, b_))
+        else:
+            xs = ops.sample_features(f.permute(0, 3, 1, 2), p_, groups)
+            out = ops.attention_core(q, None, None, p_, t, heads=h, groups=groups, views=V, precision=_lib.PREC_BF16,
+                                     kv=F.linear(xs, w, b_))
+        out.backward(cot)
+        res.append((out.detach(), [x.grad for x in ins]))
+    (of, gf), (ou, gu) = res
+    assert rel_err(of.cpu(), ou.cpu()) < 2e-2
+    for n, a, b in zip(("query", "feat", "pos", "W", "bias", "table"), gf, gu):
+        e = rel_err(a.cpu(), b.cpu())
+        print(f"[fused kv groups={groups}] grad {n} rel diff {e:.2e}")
+        assert e < 5e-2, f"grad {n}: {e:.3e}"
 
 
 @pytest.mark.gpu

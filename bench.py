@@ -434,6 +434,7 @@ def main():
         # profiles/r02_lds_*.txt; bf16 mode).
         LDS_CLK_PER_KEYROW = {"bevr_attn_fwd": 10.0,     # taps 4.8 + constants (b64 + b32 broadcast) 5.2
                               "bevr_attn_bwd_q": 22.6,   # + two ds_add_u64 12.6
+                              "bevr_attn_slab_bwd_q": 22.6,   # the same five instructions per key row and half (no window moves)
                               "bevr_attn_bwd_k": 6.0}    # per-lane tap gathers: 3 reads per 4 rows and table column
         roof_lds = []
         if args.precision == "bf16":

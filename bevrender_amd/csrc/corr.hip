@@ -8,6 +8,7 @@
 // partial dot products per thread in registers, reduces over the workgroup and adds 64 floats with
 // atomics.  (A validation-size Gram with n in the thousands is a real GEMM and belongs on MFMA: a
 // later-round row, see DESIGN.md.)
+#include <stdlib.h>
 #include "bevr_common.h"
 
 namespace {
@@ -157,8 +158,8 @@ constexpr int CORR_MAX_ROWS = 64;
 // With sqx / sqy: the rows' squared norms in the same pass (F.normalize's denominators).
 typedef __attribute__((ext_vector_type(4))) float acc4;
 
-template <int FA, int FB>
-__global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+template <int FA, int FB, int NW>
+__global__ __launch_bounds__(64 * NW) void gram_mfma_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                         float* __restrict__ dots, float* __restrict__ sqx,
                                                         float* __restrict__ sqy, int n, int m, int E) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -174,30 +175,20 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
   }
 #pragma unroll
   for (int fb = 0; fb < FB; ++fb) ny[fb] = 0.f;
-  // U 16-element steps per iteration with ALL their loads issued before the first product: a wave keeps U (FA + FB)
-  // kilobytes in flight (with 2 the kernel ran at 2.2 TB/s: one memory latency per 2 KB and wave)
-  constexpr int U = FA + FB <= 2 ? 8 : (FA + FB <= 4 ? 4 : 2);
-  const long long stride = (long long)gridDim.x * 4 * 16 * U;   // elements per grid sweep
+  const long long stride = (long long)gridDim.x * NW * 32;      // elements per grid sweep: every wave takes 32 per step
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  for (long long e0 = ((long long)blockIdx.x * 4 + wave) * 16 * U; e0 < E; e0 += stride) {
-    f32x4 a[U][FA], b[U][FB];
+  for (long long e0 = ((long long)blockIdx.x * NW + wave) * 32; e0 < E; e0 += stride) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < 2; ++u) {                                // two 16-element steps: both halves of a 128-byte line
       const long long e = e0 + 16 * u + 4 * kg;                  // E % 4 == 0: the lane's 4 elements are in or out together
+      f32x4 a[FA], b[FB];
 #pragma unroll
       for (int fa = 0; fa < FA; ++fa)
-        a[u][fa] = (e < E && 16 * fa + r < n) ? *reinterpret_cast<const f32x4*>(X + (size_t)(16 * fa + r) * E + e) : z;
-      if (!same) {
+        a[fa] = (e < E && 16 * fa + r < n) ? *reinterpret_cast<const f32x4*>(X + (size_t)(16 * fa + r) * E + e) : z;
 #pragma unroll
-        for (int fb = 0; fb < FB; ++fb)
-          b[u][fb] = (e < E && 16 * fb + r < m) ? *reinterpret_cast<const f32x4*>(Y + (size_t)(16 * fb + r) * E + e) : z;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (same) {
-#pragma unroll
-        for (int fb = 0; fb < FB; ++fb) b[u][fb] = a[u][fb < FA ? fb : 0];
+      for (int fb = 0; fb < FB; ++fb) {
+        if (same) b[fb] = a[fb < FA ? fb : 0];
+        else b[fb] = (e < E && 16 * fb + r < m) ? *reinterpret_cast<const f32x4*>(Y + (size_t)(16 * fb + r) * E + e) : z;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -205,19 +196,17 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
         for (int fa = 0; fa < FA; ++fa)
 #pragma unroll
           for (int fb = 0; fb < FB; ++fb)
-            acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][fa][q], b[u][fb][q], acc[fa][fb], 0, 0, 0);
+            acc[fa][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[fa][q], b[fb][q], acc[fa][fb], 0, 0, 0);
       if (sqx) {
 #pragma unroll
-        for (int fa = 0; fa < FA; ++fa)
-          nx[fa] += a[u][fa][0] * a[u][fa][0] + a[u][fa][1] * a[u][fa][1] + a[u][fa][2] * a[u][fa][2] + a[u][fa][3] * a[u][fa][3];
+        for (int fa = 0; fa < FA; ++fa) nx[fa] += a[fa][0] * a[fa][0] + a[fa][1] * a[fa][1] + a[fa][2] * a[fa][2] + a[fa][3] * a[fa][3];
 #pragma unroll
-        for (int fb = 0; fb < FB; ++fb)
-          ny[fb] += b[u][fb][0] * b[u][fb][0] + b[u][fb][1] * b[u][fb][1] + b[u][fb][2] * b[u][fb][2] + b[u][fb][3] * b[u][fb][3];
+        for (int fb = 0; fb < FB; ++fb) ny[fb] += b[fb][0] * b[fb][0] + b[fb][1] * b[fb][1] + b[fb][2] * b[fb][2] + b[fb][3] * b[fb][3];
       }
     }
   }
   // ---- one reduction per workgroup and 16 x 16 tile: the 4 waves through LDS, then atomics ----
-  __shared__ float red[4][256];
+  __shared__ float red[NW][256];
 #pragma unroll
   for (int fa = 0; fa < FA; ++fa)
 #pragma unroll
@@ -226,9 +215,11 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
       for (int k = 0; k < 4; ++k)   // accumulator element k of lane: row i = 4 (lane >> 4) + k, column j = lane & 15
         red[wave][(4 * kg + k) * 16 + r] = acc[fa][fb][k];
       __syncthreads();
-      {
+      if (threadIdx.x < 256) {
         const int k = threadIdx.x, i = 16 * fa + k / 16, j = 16 * fb + k % 16;
-        const float v = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][k];
         if (i < n && j < m) atomicAdd(dots + (size_t)i * m + j, v);
       }
       __syncthreads();
@@ -246,7 +237,9 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(const float* __restrict_
       if (kg == 0) red[wave][r] = v;
       __syncthreads();
       if (threadIdx.x < 16) {
-        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][threadIdx.x];
         const int row = 16 * (f < FA ? f : f - FA) + threadIdx.x;
         if (f < FA) { if (row < n) atomicAdd(sqx + row, t); }
         else if (row < m) atomicAdd(sqy + row, t);
@@ -326,42 +319,6 @@ __global__ __launch_bounds__(256) void corr_bwd_slice_kernel(const float* __rest
   auto side = [&](const float* __restrict__ Xs, const float* __restrict__ Ys, const float* __restrict__ wl,
                   const float* __restrict__ selfs, const float* __restrict__ inxs, float* __restrict__ dXs, int nxs, int nys,
                   int nxsp) {
-    if (nys <= 16 && nxs <= 16) {
-      // training batches (2B = 16 rows): the slice's rows of Y in registers, every load in flight at once, read ONCE for
-      // all row blocks; with X == Y the rows of the self term are the same registers (no second read)
-      f32x4 yv[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        yv[j] = j < nys ? *reinterpret_cast<const f32x4*>(Ys + (size_t)j * E + e) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ib = 0; ib < 16; ib += TB) {
-        if (ib >= nxs) break;
-        f32x4 acc[TB];
-#pragma unroll
-        for (int r = 0; r < TB; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          if (j >= nys) break;
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + (size_t)j * nxsp + ib);
-          const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + (size_t)j * nxsp + ib + 4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { acc[r] += yv[j] * w0[r]; acc[4 + r] += yv[j] * w1[r]; }
-        }
-#pragma unroll
-        for (int r = 0; r < TB; ++r) {
-          if (ib + r < nxs) {
-            const float sx = normalize ? inxs[ib + r] : 1.0f;
-            f32x4 v = acc[r];
-            if (normalize) {
-              const f32x4 xv = SYM ? yv[ib + r] : *reinterpret_cast<const f32x4*>(Xs + (size_t)(ib + r) * E + e);
-              v -= xv * (selfs[ib + r] * sx);
-            }
-            *reinterpret_cast<f32x4*>(dXs + (size_t)(ib + r) * E + e) = v * (-2.0f * sx);
-          }
-        }
-      }
-      return;
-    }
     for (int ib = 0; ib < nxs; ib += TB) {
       f32x4 acc[TB];
 #pragma unroll
@@ -421,10 +378,16 @@ extern "C" int bevr_corr_fwd(const float* cam, const float* map, float* D, float
     float* sqx = normalize ? inv_norm_cam : nullptr;
     float* sqy = normalize ? inv_norm_map : nullptr;
     const int fa = (n + 15) / 16, fb = (m + 15) / 16;
-    const long long want = ((long long)E + 511) / 512;           // a 128-element iteration per wave at least
-    const int grid = (int)(want < 1024 ? (want < 1 ? 1 : want) : 1024);
+    const long long want = ((long long)E + 127) / 128;           // one 32-element step per wave at least
+    const int grid = (int)(want < 512 ? (want < 1 ? 1 : want) : 512);
+    // 8 waves per workgroup: twice the bytes in flight of 4 at the same number of final atomics (a streaming read needs
+    // ~16 MB in flight to approach the HBM rate; BEVR_GRAM_WAVES=4 for A/B timing)
+    static const int nw = getenv("BEVR_GRAM_WAVES") ? atoi(getenv("BEVR_GRAM_WAVES")) : 8;
 #define BEVR_GRAM(FA_, FB_)                                                                                            \
-  hipLaunchKernelGGL((gram_mfma_kernel<FA_, FB_>), dim3(grid), dim3(256), 0, st, cam, map, D, sqx, sqy, n, m, E)
+  do {                                                                                                                 \
+    if (nw == 4) hipLaunchKernelGGL((gram_mfma_kernel<FA_, FB_, 4>), dim3(grid), dim3(256), 0, st, cam, map, D, sqx, sqy, n, m, E); \
+    else hipLaunchKernelGGL((gram_mfma_kernel<FA_, FB_, 8>), dim3(grid), dim3(512), 0, st, cam, map, D, sqx, sqy, n, m, E);         \
+  } while (0)
     if (fa == 1 && fb == 1) BEVR_GRAM(1, 1);
     else if (fa <= 2 && fb <= 2) BEVR_GRAM(2, 2);
     else BEVR_GRAM(4, 4);

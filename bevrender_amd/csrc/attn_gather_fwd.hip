@@ -9,21 +9,23 @@
 // bilinear taps of key n' in the order (y, x), (y + 1, x), (y, x + 1), (y + 1, x + 1):
 //     bias^T[n][q] = sum_slots W[n][slot] Tg[slot][q],    W[n][(n', tap)] = w_tap(n) [n' == n],
 //                                                          Tg[(n', tap)][q] = T2[A_n' + i_q + dy][X_n' + dx]
-// Tg is the B operand exactly as the lanes GATHER it: lane (q, k-group) holds the slots of two keys = two dwords (one per
-// table column, each a (y, y + 1) pair) per key -- one ds_read2_b32 per key from an LDS WINDOW of the pair table; the 16
-// lanes of a k-group read 16 consecutive rows of one column.  W is block diagonal: an LDS image that is zero except for
-// the 8 bytes (four packed weights) each key owns.  Per 16 keys x 16 BEV rows: 3 MFMAs for S (QK^T + 2 x bias), 1 for
+// Tg is the B operand exactly as the lanes GATHER it: lane (q, k-group) holds one dword (a (y, y + 1) pair) of each of four
+// keys at ONE of their two table columns -- ds_read_b32 from an LDS WINDOW of the pair table; the 16 lanes of a k-group
+// read 16 consecutive rows of one column, the two k-groups of a half wave the columns x and x + 1 of the same key, a
+// column stride = 16 (mod 32 banks) apart: no bank conflicts wherever the key lies (round 4's slot order -- two keys x two
+// columns per lane, the k-groups on DIFFERENT keys -- lost 34 % of the LDS cycles to them).  W is block diagonal: zero
+// except for the 8 bytes (four packed weights) each key owns.  Per 16 keys x 16 BEV rows: 3 MFMAs for S (QK^T + 2 x bias), 1 for
 // PV, 4 LDS gathers; no per-pair arithmetic but the exponential.
 //
 // Work split (as the tap kernels, attn_tap_fwd.hip): workgroup = ONE BEV column j of one (problem, head); wave w owns
 // the 16-row blocks [w NB, (w + 1) NB) of the column; the LAST wave is the PRODUCER.  Per emission (one 32-key tile) it
 // stages the K rows, the V rows (two 16-channel images for the transposed reads of the PV product), the W image, every
-// key's window address, and the WINDOW itself: the columns [x0, x1] x rows [a0, a0 + PITCH) of the pair table that the
-// tile's taps reach for ALL BEV rows of the column (a k-d leaf of 32 keys: ~13 columns x ~225 rows, 12 KB, one 16-byte
+// key's window address, and the WINDOW itself: the columns [x0, x1] x rows [a0, a0 + ROWS) of the pair table that the
+// tile's taps reach for ALL BEV rows of the column (a k-d leaf of 32 keys: ~13 columns x 256 rows, 13 KB, one 16-byte
 // load per lane and column).  Two buffers: the producer fills emission e + 1 while the row-block waves work on e; one
 // barrier per emission.
 //
-// ANY key set is handled: a tile whose box does not fit the window (more than WIN_COLS columns or PITCH rows) is emitted
+// ANY key set is handled: a tile whose box does not fit the window (more than WIN_COLS columns or ROWS rows) is emitted
 // in groups of 14 keys with one two-column STRIP of the table per key, the other keys masked.
 //
 // Softmax reference: STATIC.  The first pass works against the caller's mref[q] (an upper bound of the row's logits minus
@@ -56,7 +58,10 @@ namespace {
 constexpr int GT = 32;                 // keys per emission (one 32-key tile; 64: two tiles that share one window -- too
                                        // wide for WIN_COLS at the benchmark: 1.7x the emissions)
 constexpr int NT = GT / 32;
-constexpr int PITCH = 252;             // window rows (dwords) per column: ds_read2_b32 reaches the next column as offset1
+constexpr int ROWS = 256;              // window rows (dwords) per column: one 16-byte load per lane
+constexpr int PITCH = 272;             // column stride in dwords, = 16 (mod 32): the two 16-lane k-groups of a half wave read
+                                       // rows i .. i + 15 of columns x and x + 1 of ONE key -- opposite halves of the 32 banks
+                                       // of ds_read_b32, conflict-free for every key position
 constexpr int WIN_COLS = 28;
 constexpr int STRIP_KEYS = WIN_COLS / 2;
 struct LdsG {
@@ -114,13 +119,13 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
   const unsigned smem_base = (unsigned)(size_t)(lptr_t)smem;     // window addresses are handed over as LDS addresses
 
   // ---- the window fill, shared by ALL waves: entry c of a fill list = (padded table column, first table row) of window
-  // column c; wave w copies the entries w, w + n_wave, ...  One column = PITCH dwords = 63 lanes x 16 bytes, global -> LDS
+  // column c; wave w copies the entries w, w + n_wave, ...  One column = ROWS dwords = 64 lanes x 16 bytes, global -> LDS
   // directly (no registers): issued when an emission starts, waited for before its closing barrier -- the L2 latency hides
   // behind the emission's matrix work.  A table shorter than a window column (small problems) goes through registers.
   const char* tbl = reinterpret_cast<const char*>(table_pk + (size_t)hd * d.Wp * d.Hp);
   const unsigned lane16 = (unsigned)lane * 16u;
   auto fill_one = [&](char* win, int c, int xc, int r0) {      // xc, r0: uniform
-    if (lane >= PITCH / 4) return;
+    static_assert(ROWS == 256, "one 16-byte load per lane and column");
     if constexpr (DMA) {       // the launcher's choice: the table is at least a window column tall
       // scalar base + this lane's 16 bytes: no vector address arithmetic next to the accumulators
       const char* sbase = tbl + ((size_t)__builtin_amdgcn_readfirstlane(xc) * d.Hp + __builtin_amdgcn_readfirstlane(r0)) * 4;
@@ -189,8 +194,8 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
         x0 = (int)floorf(jrx + sb.bmin) + d.x_off;
         const int x1 = (int)floorf(jrx + sb.bmax) + 1 + d.x_off;
         cols = x1 - x0 + 1;
-        fits = cols <= WIN_COLS && sb.amax - sb.amin + rows_q + 1 <= PITCH;
-        a0w = max(0, min(sb.amin + d.y_off, d.Hp - PITCH));
+        fits = cols <= WIN_COLS && sb.amax - sb.amin + rows_q + 1 <= ROWS;
+        a0w = max(0, min(sb.amin + d.y_off, d.Hp - ROWS));
         rem = __ballot(live);
       }
       em.w = w_t;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
         const int rank = __builtin_popcountll(rem & ((1ull << kl) - 1ull));
         const bool mine = klane && (rem >> kl & 1ull) && rank < STRIP_KEYS;
         em.sel = __ballot(mine);
-        const int akw = max(0, min(ar, d.Hp - PITCH));
+        const int akw = max(0, min(ar, d.Hp - ROWS));
         em.koff = (2 * rank * PITCH + (ar - akw)) * 4;
         em.nfill = 2 * __builtin_popcountll(em.sel);
         // lane 2 r + c holds the entry of the key with rank r: fetch that key's (xc, akw)
@@ -317,14 +322,15 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
   f32x4 lacc[NB];         // row sum: a product of the ROUNDED weights with a ones operand (every register the same sum):
                           // O / l is then exact where one key dominates -- the backward's delta = dO . O relies on it
   float pmx[NB];          // the largest weight
-  unsigned qoff[NB];      // byte offset of the lane's BEV row in a window column
+  unsigned qoff[NB];      // byte offset of the lane's BEV row in ITS window column: k-groups 0, 2 read a key's column x,
+                          // k-groups 1, 3 column x + 1
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int row = min(blk0 + nb, nblk - 1) * QB + li;
     const size_t mcol = (size_t)j * d.Sp + row;
     qf[nb] = __builtin_bit_cast(
         bf16x8, *reinterpret_cast<const u32x4*>(Q + ((((size_t)qb * d.heads + hd) * Mp + mcol) * 32 + 8 * kg) * 2));
-    qoff[nb] = (unsigned)row * 4u;
+    qoff[nb] = (unsigned)row * 4u + (unsigned)(kg & 1) * (PITCH * 4u);
     o_lo[nb] = o_hi[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float mr = EXACT ? 0.f : mref[(size_t)ph * Mp + mcol];
     negm[nb] = f32x4{-mr, -mr, -mr, -mr};
@@ -376,25 +382,32 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
       for (int s2 = 0; s2 < 2; ++s2) {
         const int kb = 32 * t + 16 * s2;                 // first key of the sub-tile
         const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bb + L::OFF_K + kb * 64 + k_off));
-        // W: lane (key li, k-group kg) holds the slots of keys 8 m + 2 kg + {0, 1} of product m: its own key's weights or 0
-        const u32x2 w4 = *reinterpret_cast<const u32x2*>(bb + L::OFF_W + (kb + li) * 8);
-        const bool m00 = li == 2 * kg, m01 = li == 2 * kg + 1, m10 = li == 8 + 2 * kg, m11 = li == 9 + 2 * kg;
-        const u32x4 a0 = {m00 ? w4[0] : 0u, m00 ? w4[1] : 0u, m01 ? w4[0] : 0u, m01 ? w4[1] : 0u};
-        const u32x4 a1 = {m10 ? w4[0] : 0u, m10 ? w4[1] : 0u, m11 ? w4[0] : 0u, m11 ? w4[1] : 0u};
+        // Slot order of a bias product (8 keys x 4 taps = 32 slots): k-group kg holds the dwords (y, y + 1 pairs) of keys
+        // 4 (kg >> 1) + {0 .. 3} at table column x + (kg & 1).  W: lane (key li, k-group kg) holds its own key's packed
+        // weights of that column, or 0.
+        const uint32_t wsel = *reinterpret_cast<const uint32_t*>(bb + L::OFF_W + (kb + li) * 8 + 4 * (kg & 1));
+        const int kq = 4 * (kg >> 1);
+        u32x4 a0, a1;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          a0[dd] = li == kq + dd ? wsel : 0u;
+          a1[dd] = li == 8 + kq + dd ? wsel : 0u;
+        }
         const bf16x8 wa0 = __builtin_bit_cast(bf16x8, a0), wa1 = __builtin_bit_cast(bf16x8, a1);
-        // window addresses of keys 2 kg, 2 kg + 1 (first bias product) and 8 + 2 kg, 9 + 2 kg (second)
-        const u32x2 oc0 = *reinterpret_cast<const u32x2*>(bb + L::OFF_OFF + (kb + 2 * kg) * 4);
-        const u32x2 oc1 = *reinterpret_cast<const u32x2*>(bb + L::OFF_OFF + (kb + 8 + 2 * kg) * 4);
+        // window addresses of keys kq .. kq + 3 (first bias product) and 8 + kq .. 8 + kq + 3 (second)
+        const u32x4 oc0 = *reinterpret_cast<const u32x4*>(bb + L::OFF_OFF + (kb + kq) * 4);
+        const u32x4 oc1 = *reinterpret_cast<const u32x4*>(bb + L::OFF_OFF + (kb + 8 + kq) * 4);
         // both row blocks' logit chains first (independent: their matrix products interleave), then the weights.  A wave
         // whose second block lies past the column computes it on the clamped rows and drops it in the epilogue.
         f32x4 sv[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           u32x4 g0, g1;
-          const lds_u32p p0 = (lds_u32p)(uintptr_t)(oc0[0] + qoff[nb]), p1 = (lds_u32p)(uintptr_t)(oc0[1] + qoff[nb]);
-          const lds_u32p p2 = (lds_u32p)(uintptr_t)(oc1[0] + qoff[nb]), p3 = (lds_u32p)(uintptr_t)(oc1[1] + qoff[nb]);
-          g0[0] = p0[0]; g0[1] = p0[PITCH]; g0[2] = p1[0]; g0[3] = p1[PITCH];
-          g1[0] = p2[0]; g1[1] = p2[PITCH]; g1[2] = p3[0]; g1[3] = p3[PITCH];
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) {
+            g0[dd] = *(lds_u32p)(uintptr_t)(oc0[dd] + qoff[nb]);
+            g1[dd] = *(lds_u32p)(uintptr_t)(oc1[dd] + qoff[nb]);
+          }
           sv[nb] = mfma16<PREC>(kf, qf[nb], negm[nb]);
           sv[nb] = mfma16<PREC>(wa0, __builtin_bit_cast(bf16x8, g0), sv[nb]);
           sv[nb] = mfma16<PREC>(wa1, __builtin_bit_cast(bf16x8, g1), sv[nb]);
@@ -493,7 +506,7 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* V,
   const int grid = ((n_ph + 7) / 8) * 8 * d.S;
   const int nblk = (d.S + QB - 1) / QB;
   // a key's taps for all BEV rows of a column must fit one window column
-  if (nblk * QB + 1 > PITCH || nblk > 14) return BEVR_E_SHAPE;
+  if (nblk * QB + 1 > ROWS || nblk > 14) return BEVR_E_SHAPE;
   const int nb = nblk <= 7 ? 1 : 2;      // row blocks per wave: at most 7 row-block waves + the producer
   const int n_cw = (nblk + nb - 1) / nb;
   const dim3 block(64 * (n_cw + 1));
@@ -501,7 +514,7 @@ int launch(const bevr_attn_desc& d, const void* Q, const void* K, const void* V,
   hipLaunchKernelGGL((attn_gather_fwd_kernel<PREC, NB_, EX_, DMA_>), dim3(grid), block, L::TOTAL, st, d,            \
                      (const char*)Q, (const char*)K, (const char*)V, (const char*)key_ws, (const uint32_t*)table_pk, \
                      mref, O, LSE, flags)
-  const bool dma = d.Hp >= PITCH;        // else (small problems): the window columns are copied through registers
+  const bool dma = d.Hp >= ROWS;        // else (small problems): the window columns are copied through registers
   for (int ex = 0; ex < 2; ++ex) {       // static reference, then the exact pass over the flagged columns
     if (nb == 1) {
       if (dma) { if (ex) BEVR_GATHER_LAUNCH(1, true, true); else BEVR_GATHER_LAUNCH(1, false, true); }

@@ -68,8 +68,10 @@ struct LdsG {
   static constexpr int OFF_K = 0;                       // [64 keys][4 chunks of 16 B], chunk c of key n at position c ^ ((n >> 2) & 3)
   static constexpr int OFF_VLO = GT * 64;               // [64 keys][16 channels] 16-bit: channels 0..15
   static constexpr int OFF_VHI = OFF_VLO + GT * 32;     // channels 16..31
-  static constexpr int OFF_W = OFF_VHI + GT * 32;       // [64 keys] 2 dwords: packed weights of column x | x + 1, each (y, y + 1)
-  static constexpr int OFF_OFF = OFF_W + GT * 8;        // [64 keys] LDS byte address of tap (y, x) for BEV row 0
+  static constexpr int OFF_W = OFF_VHI + GT * 32;       // the W operand AS THE LANES HOLD IT: [16-key sub-tile][bias product][lane]
+                                                        // 16 bytes; zero but for one dword per (key, column): w_image_pos
+  static constexpr int W_BYTES = (GT / 16) * 2 * 64 * 16;
+  static constexpr int OFF_OFF = OFF_W + W_BYTES;       // [64 keys] LDS byte address of tap (y, x) for BEV row 0
   static constexpr int OFF_CT = OFF_OFF + GT * 4;       // u32x4: flags (bit 2: done), live keys 0..31, 32..63, entries of the fill list
   static constexpr int OFF_FD = OFF_CT + 16;            // fill list of the NEXT emission's window: [WIN_COLS] (column, first row)
   static constexpr int BUF = OFF_FD + WIN_COLS * 8;
@@ -78,12 +80,23 @@ struct LdsG {
   static constexpr int TOTAL = OFF_WIN + 2 * WIN;
 };
 static_assert(LdsG::BUF % 16 == 0 && LdsG::WIN % 16 == 0, "16-byte aligned LDS blocks");
+static_assert(2 * LdsG::TOTAL <= 160 * 1024, "two workgroups per CU");
+// Slot order of a bias product (8 keys x 4 taps = 32 slots of the contraction): k-group kg holds the dwords ((y, y + 1)
+// pairs) of keys 4 (kg >> 1) + {0 .. 3} at table column x + (kg & 1).  The A operand of product m of a 16-key sub-tile is
+// then, for lane (key li, k-group kg), dword dd = the key's packed weights of that column if li == 8 m + 4 (kg >> 1) + dd,
+// else 0: byte offset in the W image of the dword that key n (0 .. 15) owns for column c (0, 1); the other column's is
+// 256 bytes further.
+__device__ __forceinline__ int w_image_pos(int n) {
+  const int m = n >> 3, half = (n >> 2) & 1, dd = n & 3;
+  return (m * 64 + n + 32 * half) * 16 + dd * 4;
+}
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load in flight
 // (s_waitcnt vmcnt(0)): the prefetches that are meant to cross the barrier.
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 constexpr float RAISE = 40.0f;   // EXACT: binades a logit may exceed the reference before the reference moves
 
+template <int V> struct IntC { static constexpr int value = V; };
 typedef const char __attribute__((address_space(1)))* gptr_t;
 typedef char __attribute__((address_space(3)))* lptr_t;
 // 64 lanes x 16 bytes, global (per-lane address) -> LDS (base + 16 lane), no registers
@@ -144,6 +157,10 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
     for (int c = wave; c < nfill; c += n_wave) fill_one(win, c, fd[2 * c], fd[2 * c + 1]);
   };
 
+  // the W images of both buffers: zero once; the producer rewrites the dwords the keys own every emission
+  for (int i = tid; i < 2 * L::W_BYTES / 16; i += (int)blockDim.x)
+    *reinterpret_cast<u32x4*>(smem + (i / (L::W_BYTES / 16)) * L::BUF + L::OFF_W + (i % (L::W_BYTES / 16)) * 16) =
+        u32x4{0u, 0u, 0u, 0u};       // ordered before the first use by the prologue's barrier
   if (wave == n_wave - 1) {
     // ---- producer ------------------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
@@ -245,7 +262,9 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
         glds16(Vp + (n0 + n) * 64 + 32 + 16 * (lane & 1), bb + L::OFF_VHI + i * 1024);
       }
       if (klane) {
-        *reinterpret_cast<u32x2*>(bb + L::OFF_W + kl * 8) = em.w;
+        char* wk = bb + L::OFF_W + (kl >> 4) * 2048 + w_image_pos(kl & 15);
+        *reinterpret_cast<uint32_t*>(wk) = em.w[0];
+        *reinterpret_cast<uint32_t*>(wk + 256) = em.w[1];
         // a key outside the emission: any address inside the window (its logit is masked)
         const bool in = em.sel >> kl & 1ull;
         *reinterpret_cast<unsigned*>(bb + L::OFF_OFF + kl * 4) = smem_base + L::OFF_WIN + (e & 1) * L::WIN + (in ? em.koff : 0);
@@ -322,15 +341,15 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
   f32x4 lacc[NB];         // row sum: a product of the ROUNDED weights with a ones operand (every register the same sum):
                           // O / l is then exact where one key dominates -- the backward's delta = dO . O relies on it
   float pmx[NB];          // the largest weight
-  unsigned qoff[NB];      // byte offset of the lane's BEV row in ITS window column: k-groups 0, 2 read a key's column x,
-                          // k-groups 1, 3 column x + 1
+  // byte offset of the lane's BEV row (first block) in ITS window column: k-groups 0, 2 read a key's column x, k-groups
+  // 1, 3 column x + 1.  The second block's rows are QB dwords further: one ds_read2_b32 serves both blocks.
+  const unsigned qoff0 = (unsigned)(blk0 * QB + li) * 4u + (unsigned)(kg & 1) * (PITCH * 4u);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int row = min(blk0 + nb, nblk - 1) * QB + li;
     const size_t mcol = (size_t)j * d.Sp + row;
     qf[nb] = __builtin_bit_cast(
         bf16x8, *reinterpret_cast<const u32x4*>(Q + ((((size_t)qb * d.heads + hd) * Mp + mcol) * 32 + 8 * kg) * 2));
-    qoff[nb] = (unsigned)row * 4u + (unsigned)(kg & 1) * (PITCH * 4u);
     o_lo[nb] = o_hi[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float mr = EXACT ? 0.f : mref[(size_t)ph * Mp + mcol];
     negm[nb] = f32x4{-mr, -mr, -mr, -mr};
@@ -342,6 +361,7 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
   const int t_off = (4 * kg + (li >> 2)) * 32 + (lane & 3) * 8;      // transposed reads of a [key][16] image
   const int k_off = li * 64 + 16 * (kg ^ (li >> 2));                 // this lane's K fragment in a 16-key block
   typedef const uint32_t __attribute__((address_space(3)))* lds_u32p;
+  typedef const volatile uint32_t __attribute__((address_space(3)))* vlds_u32p;
 
   {   // prologue: window 0
     barrier_lds();
@@ -354,6 +374,10 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
   unsigned long long gacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long cprev = gprof_now();
 #endif
+  // the sweep over the emissions, instantiated for the distance (dwords) from the first block's window rows to the
+  // second's: QB, or 0 for the wave whose second block lies past the column (it recomputes the first and drops it)
+  auto sweep = [&](auto off1_c) {
+  constexpr int OFF1 = decltype(off1_c)::value;
   for (int e = 0;; ++e) {
     GPROF(c0);
     barrier_lds();
@@ -382,35 +406,39 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
       for (int s2 = 0; s2 < 2; ++s2) {
         const int kb = 32 * t + 16 * s2;                 // first key of the sub-tile
         const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bb + L::OFF_K + kb * 64 + k_off));
-        // Slot order of a bias product (8 keys x 4 taps = 32 slots): k-group kg holds the dwords (y, y + 1 pairs) of keys
-        // 4 (kg >> 1) + {0 .. 3} at table column x + (kg & 1).  W: lane (key li, k-group kg) holds its own key's packed
-        // weights of that column, or 0.
-        const uint32_t wsel = *reinterpret_cast<const uint32_t*>(bb + L::OFF_W + (kb + li) * 8 + 4 * (kg & 1));
+        // W as the lanes hold it (w_image_pos): two 16-byte reads, no per-lane selection
+        const bf16x8 wa0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bb + L::OFF_W + kb * 128 + lane * 16));
+        const bf16x8 wa1 =
+            __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bb + L::OFF_W + kb * 128 + 1024 + lane * 16));
         const int kq = 4 * (kg >> 1);
-        u32x4 a0, a1;
-#pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-          a0[dd] = li == kq + dd ? wsel : 0u;
-          a1[dd] = li == 8 + kq + dd ? wsel : 0u;
-        }
-        const bf16x8 wa0 = __builtin_bit_cast(bf16x8, a0), wa1 = __builtin_bit_cast(bf16x8, a1);
         // window addresses of keys kq .. kq + 3 (first bias product) and 8 + kq .. 8 + kq + 3 (second)
         const u32x4 oc0 = *reinterpret_cast<const u32x4*>(bb + L::OFF_OFF + (kb + kq) * 4);
         const u32x4 oc1 = *reinterpret_cast<const u32x4*>(bb + L::OFF_OFF + (kb + 8 + kq) * 4);
         // both row blocks' logit chains first (independent: their matrix products interleave), then the weights.  A wave
         // whose second block lies past the column computes it on the clamped rows and drops it in the epilogue.
         f32x4 sv[NB];
+        u32x4 g0[NB], g1[NB];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          const lds_u32p p0 = (lds_u32p)(uintptr_t)(oc0[dd] + qoff0), p1 = (lds_u32p)(uintptr_t)(oc1[dd] + qoff0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            // (volatile: kept from merging with the first block's read into a ds_read2_b32, whose register PAIR would have to
+            // be moved apart into the two blocks' operands -- vector instructions are what this loop is short of)
+            if (nb == 0) {
+              g0[nb][dd] = p0[0];
+              g1[nb][dd] = p1[0];
+            } else {
+              g0[nb][dd] = ((vlds_u32p)p0)[nb * OFF1];
+              g1[nb][dd] = ((vlds_u32p)p1)[nb * OFF1];
+            }
+          }
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          u32x4 g0, g1;
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) {
-            g0[dd] = *(lds_u32p)(uintptr_t)(oc0[dd] + qoff[nb]);
-            g1[dd] = *(lds_u32p)(uintptr_t)(oc1[dd] + qoff[nb]);
-          }
           sv[nb] = mfma16<PREC>(kf, qf[nb], negm[nb]);
-          sv[nb] = mfma16<PREC>(wa0, __builtin_bit_cast(bf16x8, g0), sv[nb]);
-          sv[nb] = mfma16<PREC>(wa1, __builtin_bit_cast(bf16x8, g1), sv[nb]);
+          sv[nb] = mfma16<PREC>(wa0, __builtin_bit_cast(bf16x8, g0[nb]), sv[nb]);
+          sv[nb] = mfma16<PREC>(wa1, __builtin_bit_cast(bf16x8, g1[nb]), sv[nb]);
         }
         if ((livem >> (16 * s2) & 0xffffu) != 0xffffu) {      // uniform: padding keys, or a strip emission
 #pragma unroll
@@ -461,6 +489,13 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
     wait_vm0();
     GPROF(c3);
     GPROF_ADD(2, c3 - c2);
+  }
+  };
+  if constexpr (NB == 2) {
+    if (blk0 + 1 < nblk) sweep(IntC<QB>{});
+    else sweep(IntC<0>{});
+  } else {
+    sweep(IntC<0>{});
   }
 #ifdef BEVR_GPROF
   if (lane == 0 && (wave == 0 || wave == 3)) for (int i = 0; i < 8; ++i) atomicAdd(&bevr_prof_gather[8 + (wave ? 8 : 0) + i], gacc[i]);

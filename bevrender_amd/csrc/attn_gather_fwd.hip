@@ -375,9 +375,10 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
   unsigned long long cprev = gprof_now();
 #endif
   // the sweep over the emissions, instantiated for the distance (dwords) from the first block's window rows to the
-  // second's: QB, or 0 for the wave whose second block lies past the column (it recomputes the first and drops it)
+  // second's: QB, or 0 for the wave whose second block lies past the column (it leaves that block out)
   auto sweep = [&](auto off1_c) {
   constexpr int OFF1 = decltype(off1_c)::value;
+  constexpr int NBX = (NB == 2 && OFF1 == 0) ? 1 : NB;      // that wave works on its one block only
   for (int e = 0;; ++e) {
     GPROF(c0);
     barrier_lds();
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
         for (int dd = 0; dd < 4; ++dd) {
           const lds_u32p p0 = (lds_u32p)(uintptr_t)(oc0[dd] + qoff0), p1 = (lds_u32p)(uintptr_t)(oc1[dd] + qoff0);
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
+          for (int nb = 0; nb < NBX; ++nb) {
             // (volatile: kept from merging with the first block's read into a ds_read2_b32, whose register PAIR would have to
             // be moved apart into the two blocks' operands -- vector instructions are what this loop is short of)
             if (nb == 0) {
@@ -435,20 +436,20 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
           }
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NBX; ++nb) {
           sv[nb] = mfma16<PREC>(kf, qf[nb], negm[nb]);
           sv[nb] = mfma16<PREC>(wa0, __builtin_bit_cast(bf16x8, g0[nb]), sv[nb]);
           sv[nb] = mfma16<PREC>(wa1, __builtin_bit_cast(bf16x8, g1[nb]), sv[nb]);
         }
         if ((livem >> (16 * s2) & 0xffffu) != 0xffffu) {      // uniform: padding keys, or a strip emission
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
+          for (int nb = 0; nb < NBX; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               if (!(livem >> (16 * s2 + 4 * kg + r) & 1u)) sv[nb][r] = -1.0e30f;
         }
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NBX; ++nb) {
           if constexpr (EXACT) {
             // online reference: the maximum of the row's first keys, raised (with a rescale) when a later logit exceeds it
             const float tm = fmaxf(fmaxf(sv[nb][0], sv[nb][1]), fmaxf(sv[nb][2], sv[nb][3]));
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(512, 4) void attn_gather_fwd_kernel(
         if constexpr (EXACT) first = false;
       }
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
+      for (int nb = 0; nb < NBX; ++nb) {
         const bf16x8 pb = __builtin_bit_cast(bf16x8, pw[nb]);
         o_lo[nb] = mfma16<PREC>(vlo, pb, o_lo[nb]);
         o_hi[nb] = mfma16<PREC>(vhi, pb, o_hi[nb]);

@@ -226,7 +226,6 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
     }
     return;
   }
-  float wy0[KWW];
   int arel4[KWW];
   Frag<PREC> kf[KWW], vf[KWW];
   f32x16 dk[KWW], dv[KWW];
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
 #pragma unroll
   for (int w = 0; w < KWW; ++w) {
     if (dead[w]) { A[w] = box.amin; bcl[w] = box.bmin; fy[w] = 0.f; }   // padded key: taps in the kill column => P = 0
-    wy0[w] = 1.0f - fy[w];
     arel4[w] = (A[w] - box.amin) * 4;                   // byte offset of the key's row 0 inside a ring column
     kf[w].load(Kh + (size_t)key[w] * 32 * EB, hi);
     vf[w].load(Vh + (size_t)key[w] * 32 * EB, hi);
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
       const char* p1 = reinterpret_cast<const char*>(win) + base1[w] + ioff;
       // two query rows per instruction (v_pk_*_f32): rows (k, k + 1) of a group are registers (r, r + 1), and
       // the taps are read as aligned register pairs (rows k, k+1) and (rows k+1, k+2)
-      const f32x2 wy2 = {wy0[w], wy0[w]}, fy2 = {fy[w], fy[w]}, fx2 = {fx[w], fx[w]};
+      const f32x2 fy2 = {fy[w], fy[w]}, fx2 = {fx[w], fx[w]};
       f32x2 sa2 = {0.f, 0.f}, sb2 = {0.f, 0.f};
       const int n_live = d.S - rb * 32;   // query rows of this tile inside the grid (the last tile of a column is partial)
 #pragma unroll
@@ -415,8 +413,9 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
           const float* a1 = reinterpret_cast<const float*>(p1 + o);
           const f32x2 ta = {a0[0], a0[1]}, tb = {a0[1], a0[2]};   // column X:     rows (k, k+1), (k+1, k+2)
           const f32x2 qa = {a1[0], a1[1]}, qb = {a1[1], a1[2]};   // column X + 1
-          const f32x2 u0 = ta * wy2 + tb * fy2;
-          const f32x2 u1 = qa * wy2 + qb * fy2;
+          const f32x2 d0 = tb - ta, d1 = qb - qa;                 // d / dy of the two columns
+          const f32x2 u0 = ta + fy2 * d0;                         // (1 - fy) ta + fy tb: the differences serve twice
+          const f32x2 u1 = qa + fy2 * d1;
           const f32x2 du = u1 - u0;
           const f32x2 s2 = {s[r], s[r + 1]}, dp2 = {dp[r], dp[r + 1]};
           const f32x2 sv = (s2 + u0) + fx2 * du;
@@ -425,7 +424,6 @@ __global__ __launch_bounds__(TW, 3) void attn_bwd_k_win_kernel(
           if constexpr (PREC == BEVR_PREC_F16) ds *= f32x2{c2_16, c2_16};
           s[r] = pp[0]; s[r + 1] = pp[1];
           dp[r] = ds[0]; dp[r + 1] = ds[1];
-          const f32x2 d0 = tb - ta, d1 = qb - qa;
           sa2 += ds * (d0 + fx2 * (d1 - d0));   // d bias / d a
           sb2 += ds * du;                       // d bias / d b
         }

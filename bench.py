@@ -335,7 +335,8 @@ def main():
     Hi, Wi = img_h // 4, img_w // 4
     torch.manual_seed(15213 + rank)
     model = LiftBlock(S, C, heads, D, V, L, img_w, img_h, args.precision, dev).to(dev)
-    # identical initial weights on every rank (DDP broadcasts rank 0's); one flat 25 MB bucket holds all grads
+    # identical initial weights on every rank (DDP broadcasts rank 0's); gradient buckets of a quarter of the gradient
+    # volume (parallel.wrap_data_parallel): the all-reduces of the late layers run under the early layers' backward
     net = parallel.wrap_data_parallel(model, dev_index)
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
 

@@ -123,6 +123,64 @@ def unpack_out_views(O: torch.Tensor, S: int, c: int, views: int) -> torch.Tenso
     return o.permute(0, 4, 3, 1, 2, 5).reshape(BV // views, S * S, views * h * c)
 
 
+class _MergeViews(torch.autograd.Function):
+    """merge_views below, through bevr_merge_views_fwd / _bwd (csrc/merge.hip)."""
+
+    @staticmethod
+    def forward(ctx, O_r, L_r, O_c, L_c, S, c, views):
+        _require_gpu(O_r, L_r, O_c, L_c)
+        L = _lib.lib()
+        BV, h, Mp, hd = O_r.shape
+        assert hd == HEAD_DIM and Mp % S == 0 and BV % views == 0
+        two = O_c is not None
+        O_r = O_r.float().contiguous()
+        if two:
+            O_c, L_r, L_c = O_c.float().contiguous(), L_r.float().contiguous(), L_c.float().contiguous()
+            assert O_c.shape == O_r.shape and L_r.shape == L_c.shape == O_r.shape[:3]
+        out = torch.empty(BV // views, S * S, views * h * c, device=O_r.device, dtype=torch.float32)
+        nbytes = float((O_r.numel() * (2 if two else 1)) * S / (Mp // S) * c / HEAD_DIM * 4 + out.numel() * 4)
+        _lib.check(KERNEL_TIMER.run("bevr_merge_views_fwd", 0.0, L.bevr_merge_views_fwd, _ptr(O_r),
+                                    _ptr(L_r) if two else None, _ptr(O_c) if two else None, _ptr(L_c) if two else None,
+                                    _ptr(out), BV, views, h, S, Mp // S, c, _stream(), nbytes=nbytes),
+                   "bevr_merge_views_fwd")
+        ctx.save_for_backward(*((O_r, L_r, O_c, L_c) if two else ()))
+        ctx.dims = (BV, views, h, S, Mp // S, c, two)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        BV, views, h, S, Sp, c, two = ctx.dims
+        dout = dout.float().contiguous()
+        dO_r = torch.empty(BV, h, S * Sp, HEAD_DIM, device=dout.device, dtype=torch.float32)
+        if two:
+            O_r, L_r, O_c, L_c = ctx.saved_tensors
+            dO_c, dL_r, dL_c = torch.empty_like(dO_r), torch.empty_like(L_r), torch.empty_like(L_c)
+        else:
+            O_r = L_r = O_c = L_c = dO_c = dL_r = dL_c = None
+        nbytes = float(dout.numel() * 4 * (5 if two else 2))
+        _lib.check(KERNEL_TIMER.run("bevr_merge_views_bwd", 0.0, L.bevr_merge_views_bwd, _ptr(dout), _ptr(O_r) if two else None,
+                                    _ptr(L_r) if two else None, _ptr(O_c) if two else None, _ptr(L_c) if two else None,
+                                    _ptr(dO_r), _ptr(dL_r) if two else None, _ptr(dO_c) if two else None,
+                                    _ptr(dL_c) if two else None, BV, views, h, S, Sp, c, _stream(), nbytes=nbytes),
+                   "bevr_merge_views_bwd")
+        return dO_r, dL_r, dO_c, dL_c, None, None, None
+
+
+def merge_views(O_r: torch.Tensor, S: int, c: int, views: int, L_r=None, O_c=None, L_c=None) -> torch.Tensor:
+    """The attention kernels' packed output (B * views, h, Mp, 32) -> (B, S*S, views * h * c): unpack_out_views (views = 1:
+    unpack_out) in one kernel; with a second segment (O_c, L_c and the first's L_r: the halves of one softmax over two key
+    segments, each normalised by its own log2-sum-exp) also their merge
+        O = 2^(L_r - L) O_r + 2^(L_c - L) O_c,   L = log2(2^L_r + 2^L_c)
+    in the same pass -- forward and backward (the gradients of all four inputs)."""
+    if c % 4 != 0:      # head widths the 16-byte kernel does not take: the same arithmetic as stock device ops
+        if O_c is not None:
+            L_t = torch.logaddexp2(L_r, L_c)
+            O_r = torch.exp2(L_r - L_t)[..., None] * O_r + torch.exp2(L_c - L_t)[..., None] * O_c
+        return unpack_out_views(O_r, S, c, views)
+    return _MergeViews.apply(O_r, L_r, O_c, L_c, S, c, views)
+
+
 def key_coords(pos: torch.Tensor, S: int, Wt: int, Np: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """pos (P, N, 2) in (y, x), [-1, 1] units -> table coordinates a (rows), b (cols), padded to Np.
     ty = i + a, tx = j*rx + b reproduces grid_sample(align_corners=True) of (q_grid - pos)/2
@@ -772,7 +830,7 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
             O, _ = _AttnCore.apply(Qp, None, a, b, Tt, geom, split, feat, pos.float(), Wkv, bkv, drop)
         else:
             O, _ = _AttnCore.apply(Qp, kv.float(), a, b, Tt, geom, split, None, None, None, None, drop)
-        return unpack_out_views(O, S, c, views) if concat_views else unpack_out(O, S, c)
+        return _unpacked(O, S, c, views, concat_views)
 
     # ---- keys [0, split): region kernels; keys [split, N): tap kernels; one softmax, merged through (O, LSE) ----
     V = views
@@ -799,10 +857,14 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     bv = F.pad(bkv[Cc:].float().reshape(1, heads, 1, c), (0, pad_c))
     O_c = torch.matmul(Rn, Vp) + bv
     if O_r is None:
-        return unpack_out_views(O_c, S, c, views) if concat_views else unpack_out(O_c, S, c)
-    LSE_t = torch.logaddexp2(LSE_r, LSE_c)
-    O = torch.exp2(LSE_r - LSE_t)[..., None] * O_r + torch.exp2(LSE_c - LSE_t)[..., None] * O_c
-    return unpack_out_views(O, S, c, views) if concat_views else unpack_out(O, S, c)
+        return _unpacked(O_c, S, c, views, concat_views)
+    # the two halves of the softmax merged and unpacked in one pass (csrc/merge.hip)
+    return _unpacked(O_r, S, c, views, concat_views, LSE_r, O_c, LSE_c)
+
+
+def _unpacked(O, S, c, views, concat_views, L_r=None, O_c=None, L_c=None):
+    """attention_core's return value out of the packed layout: (B, S*S, views*C) with concat_views, else (B', S*S, C)."""
+    return merge_views(O, S, c, views if concat_views else 1, L_r, O_c, L_c)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@
  *   bevr_dwconv_fwd/bwd_w   model/encoder.py:363-411, model/model_utils.py:6-35 (depthwise 3x3 of the layer glue)
  *   bevr_offset_head_fwd/bwd  model/SCA_deform_attn.py:56-77, model/TSA_deform_attn.py:54-68 (offset heads, fused)
  *   bevr_layernorm_fwd/bwd  model/model_utils.py:37-49, model/encoder.py:275 (LayerNormProxy)
+ *   bevr_merge_views_fwd/bwd  model/SCA_deform_attn.py:415-420, model/TSA_deform_attn.py:325-333 (view concat before proj_out)
  *   bevr_kv_project         model/SCA_deform_attn.py:290-321, model/TSA_deform_attn.py:210-236 (sample + proj_k | proj_v + pack)
  *   bevr_key_positions_fwd/bwd  model/SCA_deform_attn.py:248-277, model/TSA_deform_attn.py:170-196 (row split, tanh range, + ref, key order)
  *   bevr_affine_warp_fwd/bwd  model/encoder.py:413-466 (project_history_bev_feat: torchvision F.affine, twice)
@@ -50,7 +51,7 @@ extern "C" {
  *    table: a workgroup owns a slab of table columns); bevr_attn_tap_bwd_k's table operand is declared as what it always
  *    was (the plain packed table, not the pair table); bevr_kv_project takes the channel-group count (before `stream`);
  *    nothing else changed. */
-#define BEVR_ABI_VERSION 5
+#define BEVR_ABI_VERSION 6
 
 enum {
   BEVR_OK = 0,
@@ -419,6 +420,28 @@ int bevr_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
                        long long rows, int C, float eps, void* stream);
 int bevr_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* mean, const float* rstd,
                        float* dx, float* dgamma, float* dbeta, long long rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The attention output on its way to proj_out (ABI 6): the softmax merge of two key segments and the unpacking of the
+ * packed per-(problem, head) rows into the layout the projection contracts, one pass each way.  Replaces the
+ * concatenation of the per-view outputs along channels before proj_out (model/SCA_deform_attn.py:415-420) and the
+ * (B, S S, C) flattening of TSA (model/TSA_deform_attn.py:325-333); with two segments also the merge
+ *     L = log2(2^L_r + 2^L_c),  O = 2^(L_r - L) O_r + 2^(L_c - L) O_c
+ * of the halves of ONE softmax that two kernel families computed (segment r: bevr_attn_fwd / _gather_fwd (+ _cell_fwd),
+ * segment c: bevr_attn_tap_fwd + the caller's R Vpix product).
+ *   O_r, O_c, dO_r, dO_c  [n_prob][heads][S * Sp][32] float, row j * Sp + i (the attention kernels' O layout);
+ *                         n_prob = B * views, problem b * views + v;  channels c .. 31 and rows i >= S: padding
+ *   L_r, L_c, dL_r, dL_c  [n_prob][heads][S * Sp]  log2-sum-exp of the segment (LSE plane 0) and its gradient
+ *   out, dout             [B][S * S][views * heads * c], row i * S + j, channel (v * heads + hh) * c + cc
+ *   O_c == NULL: one segment (L_r, L_c, dL_r, dO_c, dL_c unused): unpack only.
+ *   backward: every element of dO_r (dO_c, dL_r, dL_c) is WRITTEN, the padding with zeros.
+ *   Sp a multiple of 32, Sp >= S; c a multiple of 4, <= 32; n_prob a multiple of views.
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_merge_views_fwd(const float* O_r, const float* L_r, const float* O_c, const float* L_c, float* out, int n_prob,
+                         int views, int heads, int S, int Sp, int c, void* stream);
+int bevr_merge_views_bwd(const float* dout, const float* O_r, const float* L_r, const float* O_c, const float* L_c,
+                         float* dO_r, float* dL_r, float* dO_c, float* dL_c, int n_prob, int views, int heads, int S,
+                         int Sp, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K | V operands straight from the feature map (16-bit operand modes): bilinear sampling at `pos` -> proj_k | proj_v

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(L, name), name
     L.bevr_abi_version.restype = ctypes.c_int
-    assert L.bevr_abi_version() == _lib.ABI_VERSION == 5
+    assert L.bevr_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_argument_contract_is_checked_without_a_gpu():

@@ -1,0 +1,72 @@
+"""bevr_merge_views_fwd / _bwd (csrc/merge.hip, ops.merge_views): the packed attention output -> the layout proj_out
+contracts, with the merge of two key segments' softmax halves -- against the stock-op chain it replaces
+(ops.unpack_out_views after logaddexp2 / exp2 / mul / add; reference model/SCA_deform_attn.py:415-420,
+model/TSA_deform_attn.py:325-333), forward and every input's gradient.  float32 both ways: the limits are rounding only."""
+import pytest
+import torch
+
+from bevrender_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel_err(got, want):
+    return (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+
+
+def _chain(O_r, L_r, O_c, L_c, S, c, views):
+    if O_c is not None:
+        L_t = torch.logaddexp2(L_r, L_c)
+        O_r = torch.exp2(L_r - L_t)[..., None] * O_r + torch.exp2(L_c - L_t)[..., None] * O_c
+    return ops.unpack_out_views(O_r, S, c, views)
+
+
+@pytest.mark.parametrize("two", [False, True])
+@pytest.mark.parametrize("B,V,h,S,c", [(2, 3, 2, 21, 32), (1, 1, 4, 40, 16), (3, 2, 1, 33, 8), (1, 6, 2, 64, 32)])
+def test_merge_views_matches_the_stock_chain(B, V, h, S, c, two):
+    gen = torch.Generator().manual_seed(S * 7 + c)
+    Sp = 32 * ((S + 31) // 32)
+    Mp = S * Sp
+
+    def mk(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=gen) * scale).to(DEV).requires_grad_(True)
+    O_r, O_c = mk(B * V, h, Mp, 32), mk(B * V, h, Mp, 32)
+    L_r, L_c = mk(B * V, h, Mp, scale=6.0), mk(B * V, h, Mp, scale=6.0)       # weights from 2^-30 to 1 - 2^-30
+    ins = (O_r, L_r, O_c, L_c) if two else (O_r,)
+    got = ops.merge_views(O_r, S, c, V, *( (L_r, O_c, L_c) if two else ()))
+    want = _chain(O_r, L_r if two else None, O_c if two else None, L_c if two else None, S, c, V)
+    assert got.shape == want.shape == (B, S * S, V * h * c)
+    assert rel_err(got, want) < 2e-6
+    cot = torch.randn(want.shape, generator=gen).to(DEV)
+    g_got = torch.autograd.grad(got, ins, cot)
+    g_want = torch.autograd.grad(want, ins, cot)
+    for name, a, b in zip(("dO_r", "dL_r", "dO_c", "dL_c") if two else ("dO_r",), g_got, g_want):
+        assert a.shape == b.shape
+        e = rel_err(a, b)
+        print(f"[merge {B=} {V=} {h=} {S=} {c=} {two=}] {name} {e:.1e}")
+        assert e < (2e-5 if name.startswith("dL") else 2e-6), (name, e)
+        # the padding (rows i >= S, channels >= c) carries exact zeros
+        if name.startswith("dO"):
+            pad = a.reshape(B * V, h, S, Sp, 32)
+            assert Sp == S or pad[:, :, :, S:, :].abs().max().item() == 0.0
+            assert c == 32 or pad[..., c:].abs().max().item() == 0.0
+
+
+def test_merge_views_ignores_what_the_padding_rows_hold():
+    """rows i >= S of the packed layout may hold anything (the kernels leave -inf / stale values there)"""
+    B, V, h, S, c = 1, 2, 2, 20, 32
+    Sp, gen = 32, torch.Generator().manual_seed(5)
+    O_r = torch.randn(B * V, h, S * Sp, 32, generator=gen).to(DEV)
+    O_c = torch.randn(B * V, h, S * Sp, 32, generator=gen).to(DEV)
+    L_r = torch.randn(B * V, h, S * Sp, generator=gen).to(DEV)
+    L_c = torch.randn(B * V, h, S * Sp, generator=gen).to(DEV)
+    clean = ops.merge_views(O_r, S, c, V, L_r, O_c, L_c)
+    for t, bad in ((O_r, float("nan")), (O_c, float("inf")), (L_r, float("-inf")), (L_c, float("-inf"))):
+        t.reshape(B * V, h, S, Sp, -1)[:, :, :, S:] = bad
+    O_r.requires_grad_(True)
+    L_r.requires_grad_(True)
+    out = ops.merge_views(O_r, S, c, V, L_r, O_c, L_c)
+    assert torch.equal(out, clean)
+    out.sum().backward()
+    assert torch.isfinite(O_r.grad).all() and torch.isfinite(L_r.grad).all()

@@ -457,7 +457,9 @@ def main():
         # loss/contrastive_loss.py:10-19): at B = 8 a (16 x 2.56 M) embedding matrix against itself -- the Gram on the f32
         # matrix cores, HBM-bound (82 MB per operand set read once; the backward reads it again and writes the
         # gradient once)
-        for k in ("bevr_kv_project", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_corr_fwd", "bevr_corr_bwd"):
+        # bevr_merge_views_fwd / _bwd: the attention output into proj_out's layout (+ the two segments' softmax merge)
+        for k in ("bevr_kv_project", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_corr_fwd", "bevr_corr_bwd",
+                  "bevr_merge_views_fwd", "bevr_merge_views_bwd"):
             if k in ktimes and ktimes[k]["ms"] > 0:
                 v = ktimes[k]
                 gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9

@@ -393,20 +393,24 @@ def cell_order(a: torch.Tensor, b: torch.Tensor, n_tail: int = 0) -> torch.Tenso
     Bc = Bc - Bc.amin(1, keepdim=True)
     nB = Bc.amax(1, keepdim=True) + 1
     snake = torch.where(A % 2 == 0, Bc, nB - 1 - Bc)
-    cid = A * nB + snake
+    # the sort keys as narrow integers: a radix sort's passes go with the key width (cell ids of a table are < 2^31,
+    # populations < 2^31, the tail flag is one byte) -- three sorts per SCA call on the product path
+    cid = (A * nB + snake).to(torch.int32)
     order = cid.argsort(1)
     if n_tail <= 0:
         return order
     P, N = cid.shape
     s = cid.gather(1, order)
-    idx = torch.arange(N, device=cid.device).expand(P, N)
-    edge = s[:, 1:] != s[:, :-1]
-    t = torch.ones(P, 1, dtype=torch.bool, device=cid.device)
-    first = torch.where(torch.cat((t, edge), 1), idx, torch.zeros_like(idx)).cummax(1).values           # run start
-    last = torch.where(torch.cat((edge, t), 1), idx, torch.full_like(idx, N)).flip(1).cummin(1).values.flip(1)  # run end
-    pop = last - first + 1                                     # population of each key's cell, in cell order
-    tail = pop.argsort(dim=1, stable=True)[:, :n_tail]             # positions (in cell order) of the sparsest cells' keys
-    flag = torch.ones(P, N, dtype=torch.int64, device=cid.device).scatter_(1, tail, 0)
+    idx = torch.arange(N, device=cid.device, dtype=torch.int32).expand(P, N)
+    # population of each key's cell, in cell order: the length of its run of equal ids (two binary searches per key)
+    pop = torch.searchsorted(s, s, right=True, out_int32=True) - torch.searchsorted(s, s, right=False, out_int32=True)
+    # positions (in cell order) of the sparsest cells' keys: the n_tail smallest of (population, position) -- what a stable
+    # sort by population would put first, selected instead of sorted
+    if N <= 65536:
+        tail = (pop.clamp(max=32767) * 65536 + idx).topk(n_tail, dim=1, largest=False, sorted=False).indices
+    else:
+        tail = pop.argsort(dim=1, stable=True)[:, :n_tail]
+    flag = torch.ones(P, N, dtype=torch.uint8, device=cid.device).scatter_(1, tail, 0)
     return order.gather(1, flag.argsort(dim=1, stable=True))       # tail first, the rest after it, both in cell order
 
 

@@ -162,3 +162,25 @@ def test_cell_order_sorts_by_cell_and_is_a_permutation():
     same_row = A[:, 1:] == A[:, :-1]
     step = (Bc[:, 1:] - Bc[:, :-1])[same_row]
     assert step.abs().max() <= 2                              # columns walk cell by cell inside a row (an empty cell: 2)
+
+
+def test_cell_order_tail_holds_the_keys_of_the_least_populated_cells():
+    """n_tail > 0: a permutation whose first n_tail keys are those of the sparsest cells (ties: earliest in cell order) and
+    whose two parts are each in cell order -- checked against a plain restatement (stable sorts on the host)."""
+    gen = torch.Generator().manual_seed(3)
+    P, N, n_tail = 4, 3000, 96
+    a = torch.randn(P, N, generator=gen) * 2.5 + 100          # clustered: populations from 1 to dozens per cell
+    b = torch.randn(P, N, generator=gen) * 3.0 + 900
+    got = ops.cell_order(a.to(DEV), b.to(DEV), n_tail).cpu()
+    base = ops.cell_order(a.to(DEV), b.to(DEV), 0).cpu()
+    assert (got.sort(1).values == torch.arange(N)[None]).all()
+    for p in range(P):
+        cid = torch.floor(a[p]).long() * 100000 + torch.floor(b[p]).long()
+        s = cid[base[p]]
+        _, inv, counts = torch.unique_consecutive(s, return_inverse=True, return_counts=True)
+        pop = counts[inv]                                         # population of each key's cell, in cell order
+        tail_pos = torch.sort(pop, stable=True).indices[:n_tail]  # the restatement: a stable sort by population
+        is_tail = torch.zeros(N, dtype=torch.bool)
+        is_tail[tail_pos] = True
+        want = torch.cat((base[p][is_tail], base[p][~is_tail]))
+        assert torch.equal(got[p], want), p

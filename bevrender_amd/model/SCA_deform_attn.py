@@ -188,6 +188,6 @@ class SCADeformableAttention(nn.Module):
                                    concat_views=True)
         # o: (B, S*S, V*C), the views side by side as proj_out contracts them (reference :415-420), written by the
         # attention's unpacking in one pass: no (B, V, M, C) -> (B, M, V C) permute copy in between
-        out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
+        out = ops.linear_rows(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
         out = F.dropout(out, self.proj_drop_rate, self.training)                      # reference :420 (proj_drop)
         return out.permute(0, 2, 1).reshape(B, C, S, S), wandb_log_dict

@@ -120,7 +120,7 @@ class TSADeformableAttention(nn.Module):
             kv = F.linear(xs, Wkv, bkv)
             o = ops.attention_core(query, None, None, pos, self.rpe_table, heads=self.n_heads, groups=self.n_groups,
                                    views=1, precision=self.precision, kv=kv, attn_drop=drop)   # (B, H*W, C)
-        out = F.linear(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
+        out = ops.linear_rows(o, self.proj_out.weight.flatten(1), self.proj_out.bias)
         out = F.dropout(out, self.proj_drop_rate, self.training)                      # reference :336 (proj_drop)
         out = out.permute(0, 2, 1).reshape(B, C, H, W)
         return out, wandb_log_dict

@@ -33,7 +33,8 @@ def depthwise_conv2d_nhwc(x, conv: nn.Conv2d):
 def pointwise_conv_nhwc(x, conv: nn.Conv2d):
     """A 1x1 `nn.Conv2d` applied to a channels-last tensor as the GEMM it is (rocBLAS).  MIOpen routes the fp32
     weight gradient of these 1x1 convolutions through its naive reference kernel (61 ms per call at 200x200)."""
-    return F.linear(x, conv.weight.flatten(1), conv.bias)
+    from .. import ops
+    return ops.linear_rows(x, conv.weight.flatten(1), conv.bias)
 
 
 class LayerNormProxy(nn.Module):

@@ -123,6 +123,52 @@ def unpack_out_views(O: torch.Tensor, S: int, c: int, views: int) -> torch.Tenso
     return o.permute(0, 4, 3, 1, 2, 5).reshape(BV // views, S * S, views * h * c)
 
 
+class _LinearRows(torch.autograd.Function):
+    """linear_rows below: F.linear forward; the weight gradient with its long contraction split (see linear_rows)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        K, N = x.shape[-1], dy.shape[-1]
+        d2, x2 = dy.reshape(-1, N), x.reshape(-1, K)
+        R = d2.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (d2 @ weight).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            nfull = R // LINEAR_ROWS_CHUNK
+            n0 = nfull * LINEAR_ROWS_CHUNK
+            dw = torch.bmm(d2[:n0].reshape(nfull, LINEAR_ROWS_CHUNK, N).transpose(1, 2),
+                           x2[:n0].reshape(nfull, LINEAR_ROWS_CHUNK, K)).sum(0)
+            if n0 < R:
+                dw = dw + d2[n0:].t() @ x2[n0:]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = d2.sum(0)
+        return dx, dw, db
+
+
+LINEAR_ROWS_CHUNK = 4096     # rows per partial product of the weight gradient
+LINEAR_ROWS_MIN = 65536      # below this many rows the stock single GEMM is as good
+
+
+def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.linear for the path's tall-and-thin products (rows = B S S = 320 000 BEV cells, 64 ... 384 channels: the 1x1
+    convolutions of the layer MLPs, model/model_utils.py:51-59, and proj_out, model/SCA_deform_attn.py:415-420).  Same
+    forward; in the backward the weight gradient dW = dY^T X -- a (N x rows) @ (rows x K) product whose output is a few
+    tiles while its contraction is 320 000 long -- is computed as rows / 4096 partial products (one batched GEMM) and
+    summed: the stock single GEMM runs it on 8 workgroups (0.7 ms per call at 64 x 256; 0.15 ms batched).  float32, same
+    results up to the order of the sum."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.numel() // x.shape[-1] < LINEAR_ROWS_MIN or not x.is_contiguous():
+        return F.linear(x, weight, bias)
+    return _LinearRows.apply(x, weight, bias)
+
+
 class _MergeViews(torch.autograd.Function):
     """merge_views below, through bevr_merge_views_fwd / _bwd (csrc/merge.hip)."""
 

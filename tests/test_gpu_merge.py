@@ -1,4 +1,6 @@
-"""bevr_merge_views_fwd / _bwd (csrc/merge.hip, ops.merge_views): the packed attention output -> the layout proj_out
+"""The attention output's way into proj_out and the tall-and-thin linears around it.
+
+bevr_merge_views_fwd / _bwd (csrc/merge.hip, ops.merge_views): the packed attention output -> the layout proj_out
 contracts, with the merge of two key segments' softmax halves -- against the stock-op chain it replaces
 (ops.unpack_out_views after logaddexp2 / exp2 / mul / add; reference model/SCA_deform_attn.py:415-420,
 model/TSA_deform_attn.py:325-333), forward and every input's gradient.  float32 both ways: the limits are rounding only."""
@@ -70,3 +72,21 @@ def test_merge_views_ignores_what_the_padding_rows_hold():
     assert torch.equal(out, clean)
     out.sum().backward()
     assert torch.isfinite(O_r.grad).all() and torch.isfinite(L_r.grad).all()
+
+
+@pytest.mark.parametrize("rows,K,N,bias", [(70000, 64, 256, True), (4096 * 17, 384, 64, True), (66001, 256, 64, False)])
+def test_linear_rows_matches_f_linear(rows, K, N, bias):
+    """ops.linear_rows: F.linear with the weight gradient's long contraction split into partial products"""
+    gen = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=gen).to(DEV).requires_grad_(True)
+    w = (torch.randn(N, K, generator=gen) * 0.1).to(DEV).requires_grad_(True)
+    b = torch.randn(N, generator=gen).to(DEV).requires_grad_(True) if bias else None
+    ins = (x, w, b) if bias else (x, w)
+    got = ops.linear_rows(x, w, b)
+    want = torch.nn.functional.linear(x, w, b)
+    assert torch.equal(got, want)
+    cot = torch.randn(want.shape, generator=gen).to(DEV)
+    for name, a, c in zip(("dx", "dw", "db"), torch.autograd.grad(got, ins, cot), torch.autograd.grad(want, ins, cot)):
+        e = rel_err(a, c)
+        print(f"[linear_rows {rows}x{K}->{N}] {name} {e:.1e}")
+        assert e < 1e-5, (name, e)      # float32 sums of 70 000 terms in two orders

@@ -116,7 +116,7 @@ def lib() -> C.CDLL:
         L.bevr_offset_head_bwd.argtypes = [fp] * 13 + [C.c_longlong] + [ip] * 4 + [C.c_float, vp]
         L.bevr_layernorm_fwd.argtypes = [fp] * 6 + [C.c_longlong, ip, C.c_float, vp]
         L.bevr_layernorm_bwd.argtypes = [fp] * 8 + [C.c_longlong, ip, vp]
-        L.bevr_kv_project.argtypes = [vp, ip, fp, C.c_longlong, vp, fp] + [ip] * 9 + [vp] * 5 + [ip, vp]
+        L.bevr_kv_project.argtypes = [vp, ip, fp, C.c_longlong, vp, fp] + [ip] * 9 + [vp] * 6 + [ip, vp]
         L.bevr_key_positions_fwd.argtypes = [fp, fp, vp, fp] + [ip] * 8 + [C.c_float, C.c_float, vp]
         L.bevr_key_positions_bwd.argtypes = [fp, fp, vp, fp, fp] + [ip] * 8 + [C.c_float, C.c_float, vp]
         L.bevr_pack_kv.argtypes = [fp, fp, C.c_longlong, C.c_longlong] + [ip] * 6 + [vp] * 5

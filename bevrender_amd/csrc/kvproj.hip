@@ -43,7 +43,8 @@ __global__ __launch_bounds__(KVP_THREADS) void kv_project_kernel(KvGeom g, const
                                                                  const float* __restrict__ bkv,      // [2C] or null
                                                                  char* __restrict__ Kr, char* __restrict__ Vr,
                                                                  char* __restrict__ Kt, char* __restrict__ Vt,
-                                                                 unsigned* __restrict__ vnorm2_max) {
+                                                                 unsigned* __restrict__ vnorm2_max,
+                                                                 unsigned* __restrict__ knorm2_max) {   // [nb][heads] or null
   extern __shared__ __attribute__((aligned(16))) char xs[];   // [64 keys][C] E, row stride C * 2 + 16
   const int C = g.C, XS = C * 2 + 16;
   const int b = blockIdx.y, n0 = blockIdx.x * KVP_KEYS, tid = threadIdx.x;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(KVP_THREADS) void kv_project_kernel(KvGeom g, const
       }
     }
     const float bias_lane = (bkv && row_ok) ? bkv[o] : 0.f;
-    float vn2 = 0.f;   // V tiles: largest squared row norm seen by this lane (the backward's scale bound)
+    float vn2 = 0.f;   // largest squared row norm seen by this lane (V: the backward's scale bound; K: the forward's)
     char* Xr = kind ? Vr : Kr;
     char* Xt = kind ? Vt : Kt;
     const size_t ph = (size_t)b * g.heads + head;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(KVP_THREADS) void kv_project_kernel(KvGeom g, const
         w.y = Half<PREC>::pack2(vv[2], vv[3]);
         *reinterpret_cast<uint2*>(dst + (8 * q4 + 4 * hi) * 2) = w;
       }
-      if (kind) vn2 = fmaxf(vn2, rn2 + __shfl_xor(rn2, 32));   // the other 16 channels sit in the other lane half
+      vn2 = fmaxf(vn2, rn2 + __shfl_xor(rn2, 32));   // the other 16 channels sit in the other lane half
       // transposed layout Xt[ph][32][Np]: this lane's channel, keys crow(r, hi) of the tile = positions 8 hi .. + 7
       // (r = 0..7) and 16 + 8 hi .. + 7 (r = 8..15) of the 32-block in its perm32 order
       if (Xt) {
@@ -150,20 +151,22 @@ __global__ __launch_bounds__(KVP_THREADS) void kv_project_kernel(KvGeom g, const
         }
       }
     }
-    if (kind && vnorm2_max) {   // non-negative floats order like their bit patterns
+    // V tiles: the launch's largest squared row norm; K tiles: the (problem, head)'s (the forward's softmax reference)
+    unsigned* nmax = kind ? vnorm2_max : (knorm2_max ? knorm2_max + ph : nullptr);
+    if (nmax) {   // non-negative floats order like their bit patterns
 #pragma unroll
       for (int sh = 16; sh > 0; sh >>= 1) vn2 = fmaxf(vn2, __shfl_xor(vn2, sh));
-      if (lane == 0) atomicMax(vnorm2_max, __builtin_bit_cast(unsigned, vn2));
+      if (lane == 0) atomicMax(nmax, __builtin_bit_cast(unsigned, vn2));
     }
   }
 }
 
 template <int PREC, typename T>
 int launch(const KvGeom& g, const T* feat, const float* pos, const void* Wkv, const float* bkv, void* Kr, void* Vr,
-           void* Kt, void* Vt, float* vn, hipStream_t st) {
+           void* Kt, void* Vt, float* vn, float* kn, hipStream_t st) {
   const size_t lds = (size_t)KVP_KEYS * (g.C * 2 + 16);
   hipLaunchKernelGGL((kv_project_kernel<PREC, T>), dim3(g.Np / KVP_KEYS, g.nb), dim3(KVP_THREADS), lds, st, g, feat, pos,
-                     (const uint32_t*)Wkv, bkv, (char*)Kr, (char*)Vr, (char*)Kt, (char*)Vt, (unsigned*)vn);
+                     (const uint32_t*)Wkv, bkv, (char*)Kr, (char*)Vr, (char*)Kt, (char*)Vt, (unsigned*)vn, (unsigned*)kn);
   return (int)hipGetLastError();
 }
 
@@ -171,8 +174,8 @@ int launch(const KvGeom& g, const T* feat, const float* pos, const void* Wkv, co
 
 extern "C" int bevr_kv_project(const void* feat, int feat_bf16, const float* pos, long long pos_pstride, const void* Wkv,
                                const float* bkv, int nb, int Hi, int Wi, int C, int N, int Np, int heads, int c,
-                               int precision, void* Kr, void* Vr, void* Kt, void* Vt, float* vnorm2_max, int groups,
-                               void* stream) {
+                               int precision, void* Kr, void* Vr, void* Kt, void* Vt, float* vnorm2_max,
+                               float* knorm2_max, int groups, void* stream) {
   if (!feat || !pos || !Wkv || !Kr || !Vr || !Vt) return BEVR_E_NULL;
   if (nb <= 0 || Hi < 2 || Wi < 2 || N <= 0 || Np < N || Np % KVP_KEYS || heads <= 0 || c <= 0 || c > 32 ||
       C != heads * c || (C & 15) || C > 256 || pos_pstride < N || groups <= 0 || C % groups || ((C / groups) & 3))
@@ -184,8 +187,8 @@ extern "C" int bevr_kv_project(const void* feat, int feat_bf16, const float* pos
   const KvGeom g{nb, Hi, Wi, C, N, Np, heads, c, pos_pstride, groups};
   hipStream_t st = (hipStream_t)stream;
   if (precision == BEVR_PREC_BF16)
-    return feat_bf16 ? launch<BEVR_PREC_BF16>(g, static_cast<const bf16_bits*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, st)
-                     : launch<BEVR_PREC_BF16>(g, static_cast<const float*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, st);
-  return feat_bf16 ? launch<BEVR_PREC_F16>(g, static_cast<const bf16_bits*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, st)
-                   : launch<BEVR_PREC_F16>(g, static_cast<const float*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, st);
+    return feat_bf16 ? launch<BEVR_PREC_BF16>(g, static_cast<const bf16_bits*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, knorm2_max, st)
+                     : launch<BEVR_PREC_BF16>(g, static_cast<const float*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, knorm2_max, st);
+  return feat_bf16 ? launch<BEVR_PREC_F16>(g, static_cast<const bf16_bits*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, knorm2_max, st)
+                   : launch<BEVR_PREC_F16>(g, static_cast<const float*>(feat), pos, Wkv, bkv, Kr, Vr, Kt, Vt, vnorm2_max, knorm2_max, st);
 }

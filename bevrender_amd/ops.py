@@ -571,12 +571,18 @@ class _AttnCore(torch.autograd.Function):
             Ve = torch.empty_like(Ke)
             Vt = torch.empty(g.n_prob, g.heads, HEAD_DIM, g.Np, device=dev, dtype=ed)
             Kt = torch.empty_like(Vt) if need_bwd else None
+            kn2 = None
             if fused:
                 nb, Hi, Wi, Cc = feat.shape
+                # the largest squared K row norm per (problem, head), out of the projection kernel: the static softmax
+                # reference of the gather forward needs it (a pass over K otherwise)
+                if not sg.cell and not ctx.drop and gather_supported(g.precision, g.S) and os.environ.get("BEVR_KNORM", "1") != "0":
+                    kn2 = torch.zeros(g.n_prob, g.heads, device=dev, dtype=torch.float32)
                 _lib.check(KERNEL_TIMER.run(
                     "bevr_kv_project", 0.0, L.bevr_kv_project, _ptr(feat), int(feat.dtype == torch.bfloat16),
                     C.c_void_p(spos.data_ptr() + sg.n0 * 8), N, _ptr(W_e), _ptr(b_f), nb, Hi, Wi, Cc, g.N, g.Np, g.heads, c,
-                    g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _ptr(vn2) if need_bwd else None, g.groups, _stream(),
+                    g.precision, _ptr(Ke), _ptr(Ve), _ptr(Kt), _ptr(Vt), _ptr(vn2) if need_bwd else None, _ptr(kn2),
+                    g.groups, _stream(),
                     nbytes=float(feat.numel() * feat.element_size() + 8 * nb * g.N + (4 if need_bwd else 3) * Ke.numel() * 2)),
                     "bevr_kv_project")
             else:
@@ -607,7 +613,10 @@ class _AttnCore(torch.autograd.Function):
                     qn = torch.linalg.vector_norm(Qe, dim=-1, dtype=torch.float32)          # (B, h, Mp)
                 # static softmax reference: |Q_q . K_n| <= ||Q_q|| max_n ||K_n||, |bias| <= max |T2| (a convex combination;
                 # 1 % for the 16-bit rounding of operands and weights), minus the headroom
-                kmx = torch.linalg.vector_norm(Ke[:, :, :g.N], dim=-1, dtype=torch.float32).amax(-1)    # (B', h)
+                if kn2 is not None:      # of the unrounded rows: the rounding is inside the 1 % below
+                    kmx = kn2.sqrt()
+                else:
+                    kmx = torch.linalg.vector_norm(Ke[:, :, :g.N], dim=-1, dtype=torch.float32).amax(-1)    # (B', h)
                 ub = 1.01 * (qn.repeat_interleave(g.q_div, 0) * kmx[..., None] + tmax[None, :, None]) + 0.01
                 mref = (ub - TAP_HEADROOM).contiguous()
                 gflags = torch.zeros(g.n_prob * g.heads * g.S, device=dev, dtype=torch.int32)

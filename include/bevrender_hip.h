@@ -459,12 +459,16 @@ int bevr_merge_views_bwd(const float* dout, const float* O_r, const float* L_r, 
  *   outputs as bevr_pack_kv: Kr, Vr [nb][heads][Np][32] E, Kt (or NULL), Vt [nb][heads][32][Np] E; keys N..Np-1 zero.
  *   vnorm2_max: one float the caller zeroed, or NULL: raised (atomic max) to the largest squared row norm of V -- the
  *            bound the backward's fixed-point scale needs (grad_scale), for free instead of a pass over V.
+ *   knorm2_max (ABI 6): [nb][heads] floats the caller zeroed, or NULL: raised (atomic max) to the largest squared row
+ *            norm of K per (problem, head) -- the gather / tap forward's static softmax reference needs max ||K_n||
+ *            (bevr_attn_gather_fwd's mref), for free instead of a pass over K.  Both norms are of the UNROUNDED rows.
  *   C = heads * c, c <= 32, C % 16 == 0, C <= 256; Np % 64 == 0.
  * The adjoint stays unfused: bevr_unpack_dkv -> GEMMs -> bevr_sample_bwd on samples recomputed with bevr_sample_fwd.
  * ---------------------------------------------------------------------------------------------- */
 int bevr_kv_project(const void* feat, int feat_bf16, const float* pos, long long pos_pstride, const void* Wkv,
                     const float* bkv, int nb, int Hi, int Wi, int C, int N, int Np, int heads, int c, int precision,
-                    void* Kr, void* Vr, void* Kt, void* Vt, float* vnorm2_max, int groups, void* stream);
+                    void* Kr, void* Vr, void* Kt, void* Vt, float* vnorm2_max, float* knorm2_max, int groups,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Key positions from the offset heads' outputs, in the attention's key order, and the adjoint (one launch each).

@@ -669,8 +669,9 @@ def test_kv_project_equals_sample_gemm_pack(shape, feat_bf16, prec):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     We = W.to(ed).contiguous()
     vn2 = torch.zeros(1, device=DEV)
+    kn2 = torch.zeros(Bp, h, device=DEV)
     rc = _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), C.c_void_p(pos.data_ptr() + n0 * 8), N, p(We), p(bias), Bp, Hi,
-                                    Wi, Cc, Ns, Np, h, c, prec, p(Kr), p(Vr), p(Kt), p(Vt), p(vn2), 1, st)
+                                    Wi, Cc, Ns, Np, h, c, prec, p(Kr), p(Vr), p(Kt), p(Vt), p(vn2), p(kn2), 1, st)
     assert rc == 0
     xs = ops._Sample.sample(feat, pos)[:, n0:]                              # float samples, the unfused kernel
     kv = (xs.to(ed).double() @ We.double().t() + bias.double()).float()     # products of E values, exact accumulation
@@ -687,16 +688,19 @@ def test_kv_project_equals_sample_gemm_pack(shape, feat_bf16, prec):
     # the largest squared V row norm, for the backward's scale bound
     want_n2 = Vw.float().pow(2).sum(-1).max().item()
     assert abs(vn2.item() - want_n2) <= 0.02 * want_n2
+    # the largest squared K row norm per (problem, head), for the forward's static softmax reference
+    want_k2 = Kw.float().pow(2).sum(-1).amax(-1)
+    assert ((kn2 - want_k2).abs() <= 0.02 * want_k2).all()
     if c < 32:
         assert (Kr[..., c:] == 0).all() and (Vt[:, :, c:] == 0).all()       # padded head channels
     # no transposed K requested (forward-only call)
     Kr2, Vr2, Vt2 = mk(Bp, h, Np, 32), mk(Bp, h, Np, 32), mk(Bp, h, 32, Np)
     assert _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), C.c_void_p(pos.data_ptr() + n0 * 8), N, p(We), p(bias), Bp,
-                                      Hi, Wi, Cc, Ns, Np, h, c, prec, p(Kr2), p(Vr2), None, p(Vt2), None, 1, st) == 0
+                                      Hi, Wi, Cc, Ns, Np, h, c, prec, p(Kr2), p(Vr2), None, p(Vt2), None, None, 1, st) == 0
     assert torch.equal(Kr2, Kr) and torch.equal(Vt2, Vt)
     # argument contract: f32-layout modes are refused
     assert _lib.lib().bevr_kv_project(p(feat), int(feat_bf16), p(pos), N, p(We), p(bias), Bp, Hi, Wi, Cc, Ns, Np, h, c,
-                                      _lib.PREC_F32, p(Kr), p(Vr), None, p(Vt), None, 1, st) == -3
+                                      _lib.PREC_F32, p(Kr), p(Vr), None, p(Vt), None, None, 1, st) == -3
 
 
 @pytest.mark.gpu

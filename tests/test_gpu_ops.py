@@ -417,7 +417,7 @@ def test_fused_offset_head_matches_the_stock_op_chain(cfg):
 
 @pytest.mark.parametrize("nhwc", [False, True])
 @pytest.mark.parametrize("shape", [(2, 8, 9, 7, 3), (1, 64, 40, 40, 3), (2, 5, 6, 11, 5), (1, 3, 4, 4, 1), (2, 256, 10, 13, 3),
-                                   (1, 16, 7, 21, 5), (3, 320, 5, 9, 3)])
+                                   (1, 16, 7, 21, 5), (3, 320, 5, 9, 3), (2, 8, 203, 200, 3), (1, 4, 30, 256, 3), (1, 4, 9, 300, 3)])
 def test_depthwise_conv_matches_torch(shape, nhwc):
     """bevr_dwconv_fwd / bwd_w (the EncoderLayer glue's depthwise convolutions) against F.conv2d(groups=C):
     forward, input gradient, weight and bias gradients; both layouts; ragged sizes; k = 1, 3, 5."""

@@ -662,26 +662,42 @@ class _AttnCore(torch.autograd.Function):
             # (~1e-7 per element) would fall into fp16's subnormals.  Every gradient is linear in dO, so the cotangent is
             # brought to ~2^10 with a power of two (exact) here and the gradients are scaled back below.  No host sync.
             sdo = torch.exp2(torch.floor(10.0 - torch.log2(dO.abs().max().clamp_min(1e-30))))
-            dO = dO * sdo
         x3 = geom.precision == _lib.PREC_BF16X3
-        dOe = _split_rows(dO.float()) if x3 else dO.to(ed).contiguous()
+        dev = dO.device
+        prep = geom.precision in (_lib.PREC_BF16, _lib.PREC_F16) and dO.dtype == torch.float32 and O.dtype == torch.float32
         # delta = rowsum(dO o O) from the SAME (rounded) dO the kernels contract with V for dP: dS = P (dP - delta) then
         # cancels as it must where P -> 1 (with the f32 dO here and the bf16 one there, |dS| kept a floor of
-        # 2^-9 |dO||V| -- pure noise in dQ, dK, d(pos), d(table) of a row dominated by one key)
-        dOr = dO.float() if x3 else dOe.float()
-        delta = (dOr * O).sum(-1)
-        if dLSE is not None:
-            # outputs (O, LSE2): d logit = ln2 P (dO . V - dO . O) + P dLSE2 = ln2 P (dP - (delta - dLSE2 / ln2))
-            dl = torch.where(torch.isfinite(LSE[0]), dLSE.float(), torch.zeros_like(delta)) * LOG2E
-            delta = delta - (dl * sdo if f16 else dl)
-        delta = delta.contiguous()
-        dev = dO.device
+        # 2^-9 |dO||V| -- pure noise in dQ, dK, d(pos), d(table) of a row dominated by one key).
+        # With outputs (O, LSE2): d logit = ln2 P (dO . V - dO . O) + P dLSE2 = ln2 P (dP - (delta - dLSE2 / ln2))
+        if prep:
+            # 16-bit modes: the rounded cotangent (rows and transposed), delta and the two maxima behind `bound` in ONE pass
+            # over dO and O (csrc/attn_bwd_prep.hip) -- seven stock passes before
+            dOe = torch.empty(O.shape, device=dev, dtype=ed)
+            dOt_p = torch.empty(geom.n_prob, geom.heads, HEAD_DIM, geom.Mp, device=dev, dtype=ed)
+            delta = torch.empty(geom.n_prob, geom.heads, geom.Mp, device=dev, dtype=torch.float32)
+            pstats = torch.zeros(2, device=dev, dtype=torch.float32)
+            dl_in = dLSE.float().contiguous() if dLSE is not None else None
+            lse0 = LSE[0].contiguous() if dLSE is not None else None
+            _lib.check(L.bevr_attn_bwd_prep(_ptr(dO), _ptr(O), _ptr(sdo) if f16 else None, _ptr(dl_in), _ptr(lse0), _ptr(dOe),
+                                            _ptr(dOt_p), _ptr(delta), _ptr(pstats), geom.n_prob * geom.heads, geom.Mp,
+                                            geom.precision, _stream()), "bevr_attn_bwd_prep")
+            dOr = None
+        else:
+            if f16:
+                dO = dO * sdo
+            dOe = _split_rows(dO.float()) if x3 else dO.to(ed).contiguous()
+            dOr = dO.float() if x3 else dOe.float()
+            delta = (dOr * O).sum(-1)
+            if dLSE is not None:
+                dl = torch.where(torch.isfinite(LSE[0]), dLSE.float(), torch.zeros_like(delta)) * LOG2E
+                delta = delta - (dl * sdo if f16 else dl)
+            delta = delta.contiguous()
         # zeros: bwd_q walks the grid in 31-row tiles and never visits the padded rows S..Sp-1 of a column; the cell
         # kernels add their segment's share
         dQ = torch.zeros(geom.n_prob, geom.heads, geom.Mp, HEAD_DIM, device=dev, dtype=torch.float32)
         dT = torch.zeros(geom.heads, geom.Wp, geom.Hp + 1, device=dev, dtype=torch.float32)
         Qt = _split_perm_t(_unsplit_rows(Qe)) if x3 else _perm_t(Qe)
-        dOt = _split_perm_t(dOr) if x3 else _perm_t(dOe)
+        dOt = dOt_p if prep else (_split_perm_t(dOr) if x3 else _perm_t(dOe))
         N, C2 = ctx.kv_shape[1], ctx.kv_shape[-1]
         dkv = torch.empty(ctx.kv_shape, device=dev, dtype=torch.float32)
         # Scales of the backward kernels (include/bevrender_hip.h, grad_scale[8]); powers of two, on the device, no sync.
@@ -698,7 +714,10 @@ class _AttnCore(torch.autograd.Function):
             vmax = ctx.vmax
         else:
             vmax = torch.stack([saved[6 * i + 1].float().norm(dim=-1).max() for i in range(len(ctx.segs))]).max()
-        bound = (dOr.norm(dim=-1).max() * vmax + delta.abs().max()).clamp_min(1e-30)
+        if prep:
+            bound = (pstats[0].sqrt() * vmax + pstats[1]).clamp_min(1e-30)
+        else:
+            bound = (dOr.norm(dim=-1).max() * vmax + delta.abs().max()).clamp_min(1e-30)
         pmax_log2 = (LSE[1].max() + 0.05).clamp(-60.0, 0.0)
         zero, one = torch.zeros((), device=dev), torch.ones((), device=dev)
         if f16:

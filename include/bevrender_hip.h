@@ -444,6 +444,23 @@ int bevr_merge_views_bwd(const float* dout, const float* O_r, const float* L_r, 
                          int Sp, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The cotangent's way into the 16-bit backward kernels (ABI 6), one pass over dO and O:
+ *   dO, O   [n_ph][Mp][32] float (n_ph = n_prob * heads): the output's cotangent and the forward's output
+ *   scale   one float on the device or NULL: a power of two applied to dO (and to dLSE) before the rounding (fp16 mode)
+ *   dLSE, LSE0  [n_ph][Mp] float or NULL: the cotangent of the log2-sum-exp output (a caller that merged this softmax with
+ *           another segment sends one) and LSE plane 0 (rows with a non-finite LSE take no dLSE)
+ *   dOe     [n_ph][Mp][32] E: the rounded rows -- the dO operand of bevr_attn_bwd_q / _slab_bwd_q / _cell_bwd_q / _bwd_k
+ *   dOt     [n_ph][32][Mp] E: the same transposed, position p of a 32-block holding row perm32(p) (bits 2 and 3 of p
+ *           swapped): the dOt operand of bevr_attn_bwd_k / _cell_bwd_k
+ *   delta   [n_ph][Mp] float: rowsum(dOe o O) - log2(e) scale dLSE: the `delta` operand of every backward entry point
+ *   stats   2 floats the caller zeroed: raised (atomic max) to max ||dOe row||^2 and max |delta| -- the bound behind
+ *           grad_scale.   Mp % 32 == 0; precision BEVR_PREC_BF16 or BEVR_PREC_F16.
+ * Replaces the autograd bookkeeping between the output's cotangent and the kernels (model/SCA_deform_attn.py:331-413).
+ * ---------------------------------------------------------------------------------------------- */
+int bevr_attn_bwd_prep(const float* dO, const float* O, const float* scale, const float* dLSE, const float* LSE0, void* dOe,
+                       void* dOt, float* delta, float* stats, int n_ph, int Mp, int precision, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K | V operands straight from the feature map (16-bit operand modes): bilinear sampling at `pos` -> proj_k | proj_v
  * as one 1x1 GEMM on the matrix cores -> the packed layouts below, in one pass; the sampled features and the projected
  * rows never reach HBM.  Replaces bevr_sample_fwd -> GEMM -> bevr_pack_kv, i.e. F.grid_sample + proj_k / proj_v + the

@@ -90,3 +90,49 @@ def test_linear_rows_matches_f_linear(rows, K, N, bias):
         e = rel_err(a, c)
         print(f"[linear_rows {rows}x{K}->{N}] {name} {e:.1e}")
         assert e < 1e-5, (name, e)      # float32 sums of 70 000 terms in two orders
+
+
+@pytest.mark.parametrize("prec_name", ["bf16", "f16"])
+@pytest.mark.parametrize("with_lse", [False, True])
+def test_attn_bwd_prep_matches_the_stock_chain(prec_name, with_lse):
+    """bevr_attn_bwd_prep (csrc/attn_bwd_prep.hip): the rounded cotangent (rows + permuted transpose), delta and the two
+    maxima, against the stock passes of ops._AttnCore.backward it replaces"""
+    import ctypes as C
+    from bevrender_amd import _lib
+    prec = _lib.PREC_BF16 if prec_name == "bf16" else _lib.PREC_F16
+    ed = torch.bfloat16 if prec_name == "bf16" else torch.float16
+    gen = torch.Generator().manual_seed(11)
+    n_prob, h, Mp = 3, 2, 7 * 32
+    dO = (torch.randn(n_prob, h, Mp, 32, generator=gen) * 3.0).to(DEV)
+    O = torch.randn(n_prob, h, Mp, 32, generator=gen).to(DEV)
+    scale = torch.tensor(4.0, device=DEV) if prec_name == "f16" else None
+    dLSE = torch.randn(n_prob, h, Mp, generator=gen).to(DEV) if with_lse else None
+    LSE0 = torch.randn(n_prob, h, Mp, generator=gen).to(DEV)
+    LSE0[0, 1, 5] = float("-inf")                                    # a row without finite LSE takes no dLSE
+    sc = 4.0 if scale is not None else 1.0
+    # the stock chain
+    dOe_w = (dO * sc).to(ed)
+    dOr = dOe_w.float()
+    delta_w = (dOr * O).sum(-1)
+    if with_lse:
+        delta_w = delta_w - torch.where(torch.isfinite(LSE0), dLSE, torch.zeros_like(dLSE)) * ops.LOG2E * sc
+    dOt_w = ops._perm_t(dOe_w)
+    # the kernel
+    dOe = torch.empty_like(dOe_w)
+    dOt = torch.empty(n_prob, h, 32, Mp, device=DEV, dtype=ed)
+    delta = torch.empty(n_prob, h, Mp, device=DEV)
+    stats = torch.zeros(2, device=DEV)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    rc = _lib.lib().bevr_attn_bwd_prep(p(dO), p(O), p(scale), p(dLSE), p(LSE0) if with_lse else None, p(dOe), p(dOt), p(delta),
+                                       p(stats), n_prob * h, Mp, prec, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dOe, dOe_w) and torch.equal(dOt, dOt_w)
+    assert rel_err(delta, delta_w) < 2e-6
+    assert abs(stats[0].item() - dOr.pow(2).sum(-1).max().item()) < 1e-5 * stats[0].item()
+    assert abs(stats[1].item() - delta_w.abs().max().item()) < 1e-5 * stats[1].item()
+    # argument contract
+    assert _lib.lib().bevr_attn_bwd_prep(p(dO), p(O), None, None, None, p(dOe), p(dOt), p(delta), p(stats), n_prob * h, Mp,
+                                         _lib.PREC_F32, None) == -3
+    assert _lib.lib().bevr_attn_bwd_prep(p(dO), p(O), None, None, None, p(dOe), p(dOt), p(delta), p(stats), n_prob * h, Mp - 1,
+                                         prec, None) == -2

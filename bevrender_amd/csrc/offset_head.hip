@@ -19,15 +19,46 @@ constexpr int OH_MAXM = 8;   // channel multiplier and output count limits (regi
 constexpr int OH_MAXD = 8;
 constexpr int OH_THREADS = 256;
 
+// Sum over the 64 lanes, the same value returned to every lane.  Data-parallel-primitive adds instead of six
+// ds_bpermute round trips (7 reductions per pixel in the forward: 42 LDS crossbar instructions): quad swaps, the two row
+// mirrors (every lane of a 16-lane row then holds the row's sum), row_bcast:15 / :31 to chain the four rows (masked rows add
+// the `old` operand, 0), and the total read off lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, r);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
-  return v;
+  v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1, 0, 3, 2]
+  v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2, 3, 0, 1]
+  v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);     // row_mirror
+  v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-__device__ __forceinline__ float gelu_erf(float y) { return 0.5f * y * (1.0f + erff(y * 0.70710678118654752f)); }
+// erf without branches (Abramowitz & Stegun 7.1.26: |error| < 1.5e-7, float rounding of the same size): the library erff
+// branches on |x| and a wave of 64 channels runs both sides -- 5 GELUs per lane and pixel made it a third of the kernel.
+// Returns erf(x) and, through e, exp(-x^2) (the gradient's Gaussian, for free).
+__device__ __forceinline__ float erf_as(float x, float& e) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  e = __expf(-ax * ax);
+  return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float y) {
+  float e;
+  return 0.5f * y * (1.0f + erf_as(y * 0.70710678118654752f, e));
+}
 __device__ __forceinline__ float gelu_erf_grad(float y) {
-  return 0.5f * (1.0f + erff(y * 0.70710678118654752f)) + y * 0.3989422804014327f * __expf(-0.5f * y * y);
+  float e;      // exp(-y^2 / 2)
+  const float er = erf_as(y * 0.70710678118654752f, e);
+  return 0.5f * (1.0f + er) + y * 0.3989422804014327f * e;
 }
 
 struct HeadParams {   // this lane's slice of the head: channel c = lane, expanded channels c*Mx .. c*Mx + Mx - 1

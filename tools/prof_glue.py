@@ -10,7 +10,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 ka = prof.key_averages(group_by_input_shape=True)
 rows = sorted(ka, key=lambda e: -e.self_device_time_total)
 tot = 0.0
-for e in rows[:90]:      # (2 steps profiled: warmup + timed)
+for e in rows[:int(os.environ.get('ROWS', '90'))]:      # (2 steps profiled: warmup + timed)
     if "attn" in e.key.lower() or "Memcpy" in e.key or "hipEvent" in e.key:
         continue
     tot += e.self_device_time_total / 2e3

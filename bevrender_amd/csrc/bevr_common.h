@@ -27,6 +27,29 @@ __host__ __device__ __forceinline__ constexpr int perm32(int r) { return (r & ~1
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// erf without branches (Abramowitz & Stegun 7.1.26: |error| < 1.5e-7, float rounding of the same size): the library erff
+// branches on |x| and a wave runs both sides (offset heads: 5 GELUs per lane and pixel were a third of the kernel).
+// Returns erf(x) and, through e, exp(-x^2) (the gradient's Gaussian, for free).
+__device__ __forceinline__ float erf_as(float x, float& e) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  e = __expf(-ax * ax);
+  return copysignf(fmaf(-p * t, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float y) {
+  float e;
+  return 0.5f * y * (1.0f + erf_as(y * 0.70710678118654752f, e));
+}
+__device__ __forceinline__ float gelu_erf_grad(float y) {
+  float e;      // exp(-y^2 / 2)
+  const float er = erf_as(y * 0.70710678118654752f, e);
+  return 0.5f * (1.0f + er) + y * 0.3989422804014327f * e;
+}
+
 // round-to-nearest-even f32 -> bf16 pair packed in one dword (plain casts lower to v_cvt_pk_bf16_f32).
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;

@@ -117,10 +117,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(DwGeom g, const float
 // filter taps in registers.
 constexpr int DW_XT = 8;
 
-template <int K>
+// MODE (the MLP's  act(y + dwc(y))  of model/model_utils.py:51-59 as one kernel each way, bevr_dwconv_res_gelu):
+//   0  y = conv(x) + bias                                   1  y = gelu(x + conv(x) + bias)
+//   2  y = aux * gelu'(x + conv(x) + bias)   (backward: the gradient at the pre-activation, recomputed, aux = d out)
+//   3  y = x + conv(x)                       (backward, flip = 1: the input gradient g + conv^T(g))
+template <int K, int MODE>
 __global__ __launch_bounds__(256) void dwconv_fwd_nhwc4_kernel(int B, int H, int W, int C, const float* __restrict__ x,
                                                                const float* __restrict__ w, const float* __restrict__ bias,
-                                                               float* __restrict__ y, int flip) {
+                                                               const float* __restrict__ aux, float* __restrict__ y, int flip) {
   constexpr int P = K / 2;
   const int c4n = C >> 2, n_xt = (W + DW_XT - 1) / DW_XT;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_nhwc4_kernel(int B, int H, int
 #pragma unroll
     for (int k = 0; k < 4; ++k) wv[tp][k] = w[(long)(c0 + k) * K * K + src];
   }
-  f32x4 acc[DW_XT];
+  f32x4 acc[DW_XT], xc[DW_XT];      // xc: the centre input of each output (MODE > 0)
   const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < DW_XT; ++i) acc[i] = b4;
@@ -157,11 +161,30 @@ __global__ __launch_bounds__(256) void dwconv_fwd_nhwc4_kernel(int B, int H, int
     for (int i = 0; i < DW_XT; ++i)
 #pragma unroll
       for (int dx = 0; dx < K; ++dx) acc[i] += row[i + dx] * wv[dy * K + dx];
+    if (MODE > 0 && dy == P) {
+#pragma unroll
+      for (int i = 0; i < DW_XT; ++i) xc[i] = row[i + P];
+    }
   }
   float* yb = y + (((long)b * H + yy) * W) * C + c0;
+  const float* ab = MODE == 2 ? aux + (((long)b * H + yy) * W) * C + c0 : nullptr;
 #pragma unroll
-  for (int i = 0; i < DW_XT; ++i)
-    if (x0 + i < W) *reinterpret_cast<f32x4*>(yb + (long)(x0 + i) * C) = acc[i];
+  for (int i = 0; i < DW_XT; ++i) {
+    if (x0 + i >= W) continue;
+    f32x4 o = acc[i];
+    if constexpr (MODE > 0) {
+      o += xc[i];
+      if constexpr (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = gelu_erf(o[k]);
+      } else if constexpr (MODE == 2) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ab + (long)(x0 + i) * C);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = a[k] * gelu_erf_grad(o[k]);
+      }
+    }
+    *reinterpret_cast<f32x4*>(yb + (long)(x0 + i) * C) = o;
+  }
 }
 
 // weight / bias gradient, channels-last.  A wave takes one image row: lane = (channel quad, x segment) -- 64 quads at
@@ -258,15 +281,37 @@ extern "C" int bevr_dwconv_fwd(const float* x, const float* w, const float* bias
     const long nthr = (long)B * H * ((W + DW_XT - 1) / DW_XT) * (C >> 2);
     const dim3 grid((unsigned)((nthr + 255) / 256));
     if (k == 3)
-      hipLaunchKernelGGL(dwconv_fwd_nhwc4_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, B, H, W, C, x, w, bias, y, flip);
+      hipLaunchKernelGGL((dwconv_fwd_nhwc4_kernel<3, 0>), grid, dim3(256), 0, (hipStream_t)stream, B, H, W, C, x, w, bias,
+                         (const float*)nullptr, y, flip);
     else
-      hipLaunchKernelGGL(dwconv_fwd_nhwc4_kernel<5>, grid, dim3(256), 0, (hipStream_t)stream, B, H, W, C, x, w, bias, y, flip);
+      hipLaunchKernelGGL((dwconv_fwd_nhwc4_kernel<5, 0>), grid, dim3(256), 0, (hipStream_t)stream, B, H, W, C, x, w, bias,
+                         (const float*)nullptr, y, flip);
     return (int)hipGetLastError();
   }
   const DwGeom g = make_geom(B, H, W, C, k, nhwc);
   const long n = (long)B * H * W * C;
   hipLaunchKernelGGL(dwconv_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, x, w, bias, y,
                      flip);
+  return (int)hipGetLastError();
+}
+
+// The MLP's  act(y + dwc(y))  (model/model_utils.py:51-59, GELU in its erf form) fused with the depthwise 3 x 3,
+// channels-last: mode 1 the forward, modes 2 and 3 the two backward kernels (see dwconv_fwd_nhwc4_kernel).
+extern "C" int bevr_dwconv_res_gelu(const float* x, const float* w, const float* bias, const float* aux, float* y, int B, int H,
+                                    int W, int C, int k, int mode, void* stream) {
+  if (!x || !w || !y || (mode == 2 && !aux)) return BEVR_E_NULL;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || k != 3 || mode < 1 || mode > 3) return BEVR_E_SHAPE;
+  if (!bevr_aligned16(x) || !bevr_aligned16(y) || (bias && !bevr_aligned16(bias)) || (aux && !bevr_aligned16(aux)))
+    return BEVR_E_ALIGN;
+  const long nthr = (long)B * H * ((W + DW_XT - 1) / DW_XT) * (C >> 2);
+  const dim3 grid((unsigned)((nthr + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 1)
+    hipLaunchKernelGGL((dwconv_fwd_nhwc4_kernel<3, 1>), grid, dim3(256), 0, st, B, H, W, C, x, w, bias, aux, y, 0);
+  else if (mode == 2)
+    hipLaunchKernelGGL((dwconv_fwd_nhwc4_kernel<3, 2>), grid, dim3(256), 0, st, B, H, W, C, x, w, bias, aux, y, 0);
+  else
+    hipLaunchKernelGGL((dwconv_fwd_nhwc4_kernel<3, 3>), grid, dim3(256), 0, st, B, H, W, C, x, w, (const float*)nullptr, aux, y, 1);
   return (int)hipGetLastError();
 }
 

@@ -38,29 +38,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// erf without branches (Abramowitz & Stegun 7.1.26: |error| < 1.5e-7, float rounding of the same size): the library erff
-// branches on |x| and a wave of 64 channels runs both sides -- 5 GELUs per lane and pixel made it a third of the kernel.
-// Returns erf(x) and, through e, exp(-x^2) (the gradient's Gaussian, for free).
-__device__ __forceinline__ float erf_as(float x, float& e) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  e = __expf(-ax * ax);
-  return copysignf(fmaf(-p * t, e, 1.0f), x);
-}
-__device__ __forceinline__ float gelu_erf(float y) {
-  float e;
-  return 0.5f * y * (1.0f + erf_as(y * 0.70710678118654752f, e));
-}
-__device__ __forceinline__ float gelu_erf_grad(float y) {
-  float e;      // exp(-y^2 / 2)
-  const float er = erf_as(y * 0.70710678118654752f, e);
-  return 0.5f * (1.0f + er) + y * 0.3989422804014327f * e;
-}
-
 struct HeadParams {   // this lane's slice of the head: channel c = lane, expanded channels c*Mx .. c*Mx + Mx - 1
   float w0[OH_MAXM], b0[OH_MAXM], ga[OH_MAXM], be[OH_MAXM], w3[OH_MAXD][OH_MAXM];
 };

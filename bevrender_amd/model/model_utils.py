@@ -70,7 +70,12 @@ class TransformerMLPWithConv(nn.Module):
     def forward(self, x):
         xh = x.permute(0, 2, 3, 1)                                  # channels-last view (a no-copy view of the
         y = self.drop1(pointwise_conv_nhwc(xh, self.linear1[0]))    # LayerNormProxy output that feeds this block)
-        y = self.act(y + depthwise_conv2d_nhwc(y, self.dwc))
+        from .. import ops
+        if isinstance(self.act, nn.GELU) and self.act.approximate == "none" and ops.dwconv_res_gelu_supported(y, self.dwc.weight) \
+                and _dw_ok(y, self.dwc):
+            y = ops.dwconv_res_gelu(y, self.dwc.weight, self.dwc.bias)      # act(y + dwc(y)) as one kernel
+        else:
+            y = self.act(y + depthwise_conv2d_nhwc(y, self.dwc))
         y = self.drop2(pointwise_conv_nhwc(y, self.linear2[0]))
         return y.permute(0, 3, 1, 2)
 

@@ -1452,6 +1452,59 @@ class _DwConv(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _DwResGelu(torch.autograd.Function):
+    """dwconv_res_gelu below (csrc/dwconv.hip, bevr_dwconv_res_gelu)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x, weight)
+        L = _lib.lib()
+        x, w = x.contiguous(), weight.contiguous()
+        b = bias.contiguous() if bias is not None else None
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        _lib.check(L.bevr_dwconv_res_gelu(_ptr(x), _ptr(w), _ptr(b), None, _ptr(y), B, H, W, Cc, 3, 1, _stream()),
+                   "bevr_dwconv_res_gelu(1)")
+        ctx.save_for_backward(x, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w, b = ctx.saved_tensors
+        L = _lib.lib()
+        B, H, W, Cc = x.shape
+        dout = dout.contiguous()
+        # the gradient at the pre-activation x + conv(x) + bias, which is recomputed (one kernel) instead of saved
+        g = torch.empty_like(x)
+        _lib.check(L.bevr_dwconv_res_gelu(_ptr(x), _ptr(w), _ptr(b), _ptr(dout), _ptr(g), B, H, W, Cc, 3, 2, _stream()),
+                   "bevr_dwconv_res_gelu(2)")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.bevr_dwconv_res_gelu(_ptr(g), _ptr(w), None, None, _ptr(dx), B, H, W, Cc, 3, 3, _stream()),
+                       "bevr_dwconv_res_gelu(3)")
+        if ctx.needs_input_grad[1] or (b is not None and ctx.needs_input_grad[2]):
+            dw = torch.zeros_like(w)
+            db = torch.zeros(Cc, device=x.device, dtype=x.dtype) if b is not None else None
+            _lib.check(L.bevr_dwconv_bwd_w(_ptr(x), _ptr(g), _ptr(dw), _ptr(db), B, H, W, Cc, 3, 1, _stream()),
+                       "bevr_dwconv_bwd_w")
+        return dx, dw, db
+
+
+def dwconv_res_gelu_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[-1] % 4 == 0 and weight.shape[-1] == 3
+            and weight.shape[-2] == 3 and weight.shape[1] == 1 and weight.shape[0] == x.shape[-1]
+            and os.environ.get("BEVR_FUSED_MLP", "1") != "0")
+
+
+def dwconv_res_gelu(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
+    """gelu(x + depthwise3x3(x) + bias) on a channels-last (B, H, W, C) tensor, GELU in its erf form: the middle of the
+    layer MLPs (reference model/model_utils.py:51-59: `act(x + dwc(x))`) as ONE kernel in the forward (three stock passes:
+    convolution, add, GELU) and three in the backward (pre-activation gradient recomputed from x, input gradient with
+    the residual folded in, weight gradient), nothing saved but x.  BEVR_FUSED_MLP=0: the unfused chain."""
+    return _DwResGelu.apply(x, weight, bias)
+
+
 def depthwise_conv(x: torch.Tensor, weight: torch.Tensor, bias, nhwc: bool) -> torch.Tensor:
     """Depthwise k x k (k odd <= 5), stride 1, 'same' padding.  x (B,H,W,C) if nhwc else (B,C,H,W) float32;
     weight (C,1,k,k) as in nn.Conv2d(groups=C); bias (C,) or None."""

@@ -393,6 +393,14 @@ int bevr_dwconv_fwd(const float* x, const float* w, const float* bias, float* y,
                     int B, int H, int W, int C, int k, int nhwc, int flip, void* stream);
 int bevr_dwconv_bwd_w(const float* x, const float* dy, float* dw, float* dbias,
                       int B, int H, int W, int C, int k, int nhwc, void* stream);
+/* The MLP's  act(y + dwc(y))  of model/model_utils.py:51-59 (nn.GELU, erf form) with the depthwise 3 x 3, one kernel
+ * (ABI 6; channels-last [B][H][W][C], C % 4 == 0, k = 3):
+ *   mode 1  y = gelu(x + conv(x) + bias)                               the forward
+ *   mode 2  y = aux * gelu'(x + conv(x) + bias)                        backward: gradient at the pre-activation (aux = d out)
+ *   mode 3  y = x + conv^T(x)    (flipped filter, bias ignored)        backward: the input gradient from mode 2's result
+ * The weight / bias gradients are bevr_dwconv_bwd_w(x, <mode 2's result>). */
+int bevr_dwconv_res_gelu(const float* x, const float* w, const float* bias, const float* aux, float* y, int B, int H, int W,
+                         int C, int k, int mode, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Operand packing for bevr_attn_* (the reshapes of model/SCA_deform_attn.py:312-321 / TSA_deform_attn.py:226-236:

@@ -136,3 +136,23 @@ def test_attn_bwd_prep_matches_the_stock_chain(prec_name, with_lse):
                                          _lib.PREC_F32, None) == -3
     assert _lib.lib().bevr_attn_bwd_prep(p(dO), p(O), None, None, None, p(dOe), p(dOt), p(delta), p(stats), n_prob * h, Mp - 1,
                                          prec, None) == -2
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 7, 8), (1, 40, 40, 64), (2, 10, 13, 256), (1, 203, 200, 12)])
+def test_dwconv_res_gelu_matches_the_stock_chain(shape):
+    """ops.dwconv_res_gelu (bevr_dwconv_res_gelu): gelu(x + depthwise3x3(x) + bias), the middle of the layer MLPs
+    (reference model/model_utils.py:51-59), against conv2d + add + F.gelu -- forward and all three gradients"""
+    B, H, W, Cc = shape
+    gen = torch.Generator().manual_seed(H * 3 + Cc)
+    x = torch.randn(B, H, W, Cc, generator=gen).to(DEV).requires_grad_(True)
+    w = (torch.randn(Cc, 1, 3, 3, generator=gen) * 0.3).to(DEV).requires_grad_(True)
+    b = torch.randn(Cc, generator=gen).to(DEV).requires_grad_(True)
+    got = ops.dwconv_res_gelu(x, w, b)
+    xn = x.permute(0, 3, 1, 2)
+    want = torch.nn.functional.gelu(xn + torch.nn.functional.conv2d(xn, w, b, padding=1, groups=Cc)).permute(0, 2, 3, 1)
+    assert rel_err(got, want) < 2e-6
+    cot = torch.randn(want.shape, generator=gen).to(DEV)
+    for name, a, c in zip(("dx", "dw", "db"), torch.autograd.grad(got, (x, w, b), cot), torch.autograd.grad(want, (x, w, b), cot)):
+        e = rel_err(a, c)
+        print(f"[dwconv_res_gelu {shape}] {name} {e:.1e}")
+        assert e < 2e-5, (name, e)

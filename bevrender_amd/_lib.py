@@ -28,7 +28,7 @@ SYMBOLS = [
     "bevr_attn_fwd", "bevr_attn_bwd_q",
     "bevr_attn_bwd_k", "bevr_attn_fwd_dropout", "bevr_attn_bwd_q_dropout", "bevr_attn_bwd_k_dropout", "bevr_attn_cell_fwd", "bevr_attn_cell_bwd_q", "bevr_attn_cell_bwd_k", "bevr_attn_tap_ws_bytes", "bevr_attn_tap_prep", "bevr_attn_tap_fwd", "bevr_attn_tap_bwd_q", "bevr_attn_tap_bwd_k", "bevr_attn_gather_fwd", "bevr_attn_slab_ws_bytes", "bevr_attn_slab_prep", "bevr_attn_slab_bwd_q", "bevr_sample_fwd", "bevr_sample_bwd", "bevr_sample_fwd_bf16", "bevr_sample_bwd_bf16", "bevr_project_bev_grid", "bevr_project_bev_grid_masked", "bevr_corr_fwd",
     "bevr_corr_bwd", "bevr_recall_rank", "bevr_dwconv_fwd", "bevr_dwconv_bwd_w", "bevr_dwconv_res_gelu", "bevr_affine_warp_fwd", "bevr_affine_warp_bwd",
-    "bevr_offset_head_fwd", "bevr_offset_head_bwd", "bevr_key_positions_fwd", "bevr_key_positions_bwd", "bevr_kv_project", "bevr_layernorm_fwd", "bevr_layernorm_bwd", "bevr_merge_views_fwd", "bevr_merge_views_bwd", "bevr_attn_bwd_prep", "bevr_pack_kv", "bevr_unpack_dkv",
+    "bevr_offset_head_fwd", "bevr_offset_head_bwd", "bevr_key_positions_fwd", "bevr_key_positions_bwd", "bevr_kv_project", "bevr_layernorm_fwd", "bevr_layernorm_bwd", "bevr_merge_views_fwd", "bevr_merge_views_bwd", "bevr_merge_tap_fwd", "bevr_merge_tap_bwd", "bevr_attn_bwd_prep", "bevr_pack_kv", "bevr_unpack_dkv",
 ]
 
 
@@ -123,6 +123,8 @@ def lib() -> C.CDLL:
         L.bevr_pack_kv.argtypes = [fp, fp, C.c_longlong, C.c_longlong] + [ip] * 6 + [vp] * 5
         L.bevr_merge_views_fwd.argtypes = [fp] * 5 + [ip] * 6 + [vp]
         L.bevr_merge_views_bwd.argtypes = [fp] * 9 + [ip] * 6 + [vp]
+        L.bevr_merge_tap_fwd.argtypes = [fp] * 7 + [ip] * 6 + [vp]
+        L.bevr_merge_tap_bwd.argtypes = [fp] * 13 + [ip] * 6 + [vp]
         L.bevr_attn_bwd_prep.argtypes = [fp] * 5 + [vp, vp, fp, fp] + [ip] * 3 + [vp]
         L.bevr_unpack_dkv.argtypes = [fp] * 4 + [C.c_longlong, C.c_longlong] + [ip] * 5 + [vp]
         for name in SYMBOLS:

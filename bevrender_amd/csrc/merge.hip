@@ -163,3 +163,185 @@ extern "C" int bevr_merge_views_bwd(const float* dout, const float* O_r, const f
                        O_c, L_c, dO_r, dL_r, dO_c, dL_c, n_thr);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same merge with the tap segment's half NOT materialised: the tap kernels hand over Rn[ph][m][12] (the softmax
+// weights summed per pixel tap, normalised) and the caller the 12 pixels' value rows Vp[ph][12][32] and the value bias
+// bv[heads][32]:   O_c = Rn Vp + bv   (csrc/attn_tap.h: V_n = sum_t w_t(n) Vpix_t + bv) is formed in registers on the
+// way -- a (M x 12) x (12 x 32) product per (problem, head) and an add that were two more passes over the packed output,
+// and in the backward two thin batched GEMMs and a row sum.  A workgroup stays inside one (problem, head): Vp sits in
+// registers, the backward's dVp / dbv partial sums too (one atomic per element and workgroup at the end).
+namespace {
+
+constexpr int MT_CHUNKS = 32;      // workgroups per (problem, head)
+
+__device__ __forceinline__ float add8(float v) {      // sum over the 8 lanes of a row (lanes 8 k .. 8 k + 7)
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // ^1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // ^2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // 7 - i
+  return v;
+}
+
+struct TapRow { f32x4 r0, r1, r2; };      // Rn[row][0 .. 11]
+__device__ __forceinline__ f32x4 tap_oc(const TapRow& rn, const f32x4 (&vp)[12], const f32x4& bv4) {
+  f32x4 o = bv4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    o += vp[t] * rn.r0[t];
+    o += vp[4 + t] * rn.r1[t];
+    o += vp[8 + t] * rn.r2[t];
+  }
+  return o;
+}
+
+__global__ __launch_bounds__(MG_THREADS) void merge_tap_fwd_kernel(MergeGeom g, const float* __restrict__ O_r,
+                                                                   const float* __restrict__ L_r, const float* __restrict__ Rn,
+                                                                   const float* __restrict__ L_c, const float* __restrict__ Vp,
+                                                                   const float* __restrict__ bv, float* __restrict__ out) {
+  const int Mp = g.S * g.Sp;
+  const int bvh = blockIdx.x, hh = bvh % g.heads, bvi = bvh / g.heads;
+  const int b = bvi / g.views, v = bvi - b * g.views;
+  const int c4 = threadIdx.x & 7, r32 = threadIdx.x >> 3;
+  f32x4 vp[12];
+#pragma unroll
+  for (int t = 0; t < 12; ++t) vp[t] = *reinterpret_cast<const f32x4*>(Vp + ((size_t)bvh * 12 + t) * 32 + 4 * c4);
+  const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bv + hh * 32 + 4 * c4);
+  const int per = ((Mp / 32 + MT_CHUNKS - 1) / MT_CHUNKS) * 32, m0 = blockIdx.y * per, m1 = min(Mp, m0 + per);
+  for (int mq = m0 + r32; mq < m1; mq += 32) {
+    const int j = mq / g.Sp, i = mq - j * g.Sp;
+    if (i >= g.S || 4 * c4 >= g.c) continue;
+    const size_t row = (size_t)bvh * Mp + mq;
+    const f32x4 orr = *reinterpret_cast<const f32x4*>(O_r + row * 32 + 4 * c4);
+    TapRow rn;
+    rn.r0 = *reinterpret_cast<const f32x4*>(Rn + row * 12);
+    rn.r1 = *reinterpret_cast<const f32x4*>(Rn + row * 12 + 4);
+    rn.r2 = *reinterpret_cast<const f32x4*>(Rn + row * 12 + 8);
+    const f32x4 oc = tap_oc(rn, vp, bv4);
+    const float lr = L_r[row], lc = L_c[row];
+    const float mx = fmaxf(lr, lc);
+    const float er = exp2f(lr - mx), ec = exp2f(lc - mx);
+    const float inv = 1.0f / (er + ec);
+    const size_t oidx = ((size_t)b * g.S * g.S + (size_t)i * g.S + j) * ((size_t)g.views * g.heads * g.c) +
+                        (size_t)(v * g.heads + hh) * g.c + 4 * c4;
+    *reinterpret_cast<f32x4*>(out + oidx) = orr * (er * inv) + oc * (ec * inv);
+  }
+}
+
+__global__ __launch_bounds__(MG_THREADS) void merge_tap_bwd_kernel(MergeGeom g, const float* __restrict__ dout,
+                                                                   const float* __restrict__ O_r, const float* __restrict__ L_r,
+                                                                   const float* __restrict__ Rn, const float* __restrict__ L_c,
+                                                                   const float* __restrict__ Vp, const float* __restrict__ bv,
+                                                                   float* __restrict__ dO_r, float* __restrict__ dL_r,
+                                                                   float* __restrict__ dRn, float* __restrict__ dL_c,
+                                                                   float* __restrict__ dVp, float* __restrict__ dbv) {
+  __shared__ f32x4 red[13][MG_THREADS];
+  const int Mp = g.S * g.Sp;
+  const int bvh = blockIdx.x, hh = bvh % g.heads, bvi = bvh / g.heads;
+  const int b = bvi / g.views, v = bvi - b * g.views;
+  const int c4 = threadIdx.x & 7, r32 = threadIdx.x >> 3;
+  f32x4 vp[12], acc[12], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 12; ++t) {
+    vp[t] = *reinterpret_cast<const f32x4*>(Vp + ((size_t)bvh * 12 + t) * 32 + 4 * c4);
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bv + hh * 32 + 4 * c4);
+  const bool c_live = 4 * c4 < g.c;
+  const int per = ((Mp / 32 + MT_CHUNKS - 1) / MT_CHUNKS) * 32, m0 = blockIdx.y * per, m1 = min(Mp, m0 + per);
+  // (whole rows of 8 lanes run the loop together: m0, m1 and the step are multiples of 32, Mp too)
+  for (int mq = m0 + r32; mq < m1; mq += 32) {
+    const int j = mq / g.Sp, i = mq - j * g.Sp;
+    const bool row_live = i < g.S;
+    const size_t row = (size_t)bvh * Mp + mq;
+    f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+    if (row_live && c_live) {
+      const size_t oidx = ((size_t)b * g.S * g.S + (size_t)i * g.S + j) * ((size_t)g.views * g.heads * g.c) +
+                          (size_t)(v * g.heads + hh) * g.c + 4 * c4;
+      gq = *reinterpret_cast<const f32x4*>(dout + oidx);
+    }
+    const f32x4 orr = *reinterpret_cast<const f32x4*>(O_r + row * 32 + 4 * c4);
+    TapRow rn;
+    rn.r0 = *reinterpret_cast<const f32x4*>(Rn + row * 12);
+    rn.r1 = *reinterpret_cast<const f32x4*>(Rn + row * 12 + 4);
+    rn.r2 = *reinterpret_cast<const f32x4*>(Rn + row * 12 + 8);
+    const f32x4 oc = tap_oc(rn, vp, bv4);
+    const float lr = L_r[row], lc = L_c[row];
+    const float mx = fmaxf(lr, lc);
+    const float er = exp2f(lr - mx), ec = exp2f(lc - mx);
+    const float inv = 1.0f / (er + ec);
+    const float ar = row_live ? er * inv : 0.f, ac = row_live ? ec * inv : 0.f;
+    *reinterpret_cast<f32x4*>(dO_r + row * 32 + 4 * c4) = gq * ar;
+    const f32x4 goc = gq * ac;      // gradient of O_c
+    const f32x4 df = orr - oc;
+    const float p = add8(gq[0] * df[0] + gq[1] * df[1] + gq[2] * df[2] + gq[3] * df[3]);
+    // d Rn[t] = sum_c goc[c] Vp[t][c]: this lane's four channels, then the row's eight lanes
+    float dr[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+      dr[t] = add8(goc[0] * vp[t][0] + goc[1] * vp[t][1] + goc[2] * vp[t][2] + goc[3] * vp[t][3]);
+    // lane c4 writes elements c4 and (c4 < 4) 8 + c4 of the row
+    float w0 = dr[0], w1 = dr[8];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) w0 = c4 == t ? dr[t] : w0;
+#pragma unroll
+    for (int t = 1; t < 4; ++t) w1 = c4 == t ? dr[8 + t] : w1;
+    dRn[row * 12 + c4] = w0;
+    if (c4 < 4) dRn[row * 12 + 8 + c4] = w1;
+    if (c4 == 0) {
+      const float gl = row_live ? 0.6931471805599453f * ar * ac * p : 0.f;
+      dL_r[row] = gl;
+      dL_c[row] = -gl;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[t] += goc * rn.r0[t];
+      acc[4 + t] += goc * rn.r1[t];
+      acc[8 + t] += goc * rn.r2[t];
+    }
+    accb += goc;
+  }
+  // the workgroup's 32 row slots summed through LDS; one atomic per element of dVp / dbv and workgroup
+#pragma unroll
+  for (int t = 0; t < 12; ++t) red[t][threadIdx.x] = acc[t];
+  red[12][threadIdx.x] = accb;
+  __syncthreads();
+  for (int e = threadIdx.x; e < 13 * 8; e += MG_THREADS) {
+    const int t = e >> 3, q = e & 7;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 32; ++r) s += red[t][r * 8 + q];
+    float* dst = t < 12 ? dVp + ((size_t)bvh * 12 + t) * 32 + 4 * q : dbv + hh * 32 + 4 * q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(dst + k, s[k]);
+  }
+}
+
+}  // namespace
+
+extern "C" int bevr_merge_tap_fwd(const float* O_r, const float* L_r, const float* Rn, const float* L_c, const float* Vp,
+                                  const float* bv, float* out, int n_prob, int views, int heads, int S, int Sp, int c,
+                                  void* stream) {
+  const int rc = merge_check(n_prob, views, heads, S, Sp, c);
+  if (rc) return rc;
+  if (!O_r || !L_r || !Rn || !L_c || !Vp || !bv || !out) return BEVR_E_NULL;
+  if (!bevr_aligned16(O_r) || !bevr_aligned16(Rn) || !bevr_aligned16(Vp) || !bevr_aligned16(bv) || !bevr_aligned16(out))
+    return BEVR_E_ALIGN;
+  const MergeGeom g = {n_prob, views, heads, S, Sp, c};
+  hipLaunchKernelGGL(merge_tap_fwd_kernel, dim3(n_prob * heads, MT_CHUNKS), dim3(MG_THREADS), 0, (hipStream_t)stream, g, O_r,
+                     L_r, Rn, L_c, Vp, bv, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int bevr_merge_tap_bwd(const float* dout, const float* O_r, const float* L_r, const float* Rn, const float* L_c,
+                                  const float* Vp, const float* bv, float* dO_r, float* dL_r, float* dRn, float* dL_c,
+                                  float* dVp, float* dbv, int n_prob, int views, int heads, int S, int Sp, int c, void* stream) {
+  const int rc = merge_check(n_prob, views, heads, S, Sp, c);
+  if (rc) return rc;
+  if (!dout || !O_r || !L_r || !Rn || !L_c || !Vp || !bv || !dO_r || !dL_r || !dRn || !dL_c || !dVp || !dbv) return BEVR_E_NULL;
+  if (!bevr_aligned16(dout) || !bevr_aligned16(O_r) || !bevr_aligned16(Rn) || !bevr_aligned16(Vp) || !bevr_aligned16(bv) ||
+      !bevr_aligned16(dO_r))
+    return BEVR_E_ALIGN;
+  const MergeGeom g = {n_prob, views, heads, S, Sp, c};
+  hipLaunchKernelGGL(merge_tap_bwd_kernel, dim3(n_prob * heads, MT_CHUNKS), dim3(MG_THREADS), 0, (hipStream_t)stream, g, dout,
+                     O_r, L_r, Rn, L_c, Vp, bv, dO_r, dL_r, dRn, dL_c, dVp, dbv);
+  return (int)hipGetLastError();
+}

@@ -213,6 +213,49 @@ class _MergeViews(torch.autograd.Function):
         return dO_r, dL_r, dO_c, dL_c, None, None, None
 
 
+class _MergeTap(torch.autograd.Function):
+    """merge_tap below, through bevr_merge_tap_fwd / _bwd (csrc/merge.hip)."""
+
+    @staticmethod
+    def forward(ctx, O_r, L_r, Rn, L_c, Vp, bv, S, c, views):
+        _require_gpu(O_r, L_r, Rn, L_c, Vp, bv)
+        L = _lib.lib()
+        BV, h, Mp, hd = O_r.shape
+        assert hd == HEAD_DIM and Mp % S == 0 and BV % views == 0 and Rn.shape == (BV, h, Mp, TAP_N)
+        assert Vp.shape == (BV, h, TAP_N, HEAD_DIM) and bv.shape == (h, HEAD_DIM)
+        O_r, L_r, Rn, L_c, Vp, bv = (t.float().contiguous() for t in (O_r, L_r, Rn, L_c, Vp, bv))
+        out = torch.empty(BV // views, S * S, views * h * c, device=O_r.device, dtype=torch.float32)
+        live = S / (Mp // S)
+        nbytes = float(O_r.numel() * live * (c / HEAD_DIM + TAP_N / HEAD_DIM) * 4 + out.numel() * 4)
+        _lib.check(KERNEL_TIMER.run("bevr_merge_views_fwd", 0.0, L.bevr_merge_tap_fwd, _ptr(O_r), _ptr(L_r), _ptr(Rn), _ptr(L_c),
+                                    _ptr(Vp), _ptr(bv), _ptr(out), BV, views, h, S, Mp // S, c, _stream(), nbytes=nbytes),
+                   "bevr_merge_tap_fwd")
+        ctx.save_for_backward(O_r, L_r, Rn, L_c, Vp, bv)
+        ctx.dims = (BV, views, h, S, Mp // S, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        BV, views, h, S, Sp, c = ctx.dims
+        O_r, L_r, Rn, L_c, Vp, bv = ctx.saved_tensors
+        dout = dout.float().contiguous()
+        dO_r, dL_r, dRn, dL_c = torch.empty_like(O_r), torch.empty_like(L_r), torch.empty_like(Rn), torch.empty_like(L_c)
+        dVp, dbv = torch.zeros_like(Vp), torch.zeros_like(bv)
+        nbytes = float(dout.numel() * 4 * (3 + 2 * TAP_N / HEAD_DIM))
+        _lib.check(KERNEL_TIMER.run("bevr_merge_views_bwd", 0.0, L.bevr_merge_tap_bwd, _ptr(dout), _ptr(O_r), _ptr(L_r), _ptr(Rn),
+                                    _ptr(L_c), _ptr(Vp), _ptr(bv), _ptr(dO_r), _ptr(dL_r), _ptr(dRn), _ptr(dL_c), _ptr(dVp),
+                                    _ptr(dbv), BV, views, h, S, Sp, c, _stream(), nbytes=nbytes), "bevr_merge_tap_bwd")
+        return dO_r, dL_r, dRn, dL_c, dVp, dbv, None, None, None
+
+
+def merge_tap(O_r, L_r, Rn, L_c, Vp, bv, S: int, c: int, views: int) -> torch.Tensor:
+    """merge_views with the tap segment's half formed on the way: O_c = Rn Vp + bv is never materialised (Rn (B', h, Mp, 12)
+    the tap kernels' normalised weight sums, Vp (B', h, 12, 32) the 12 pixels' value rows, bv (h, 32) the value bias: the
+    thin product, the add and, in the backward, two thin batched GEMMs and a row sum join the one pass each way)."""
+    return _MergeTap.apply(O_r, L_r, Rn, L_c, Vp, bv, S, c, views)
+
+
 def merge_views(O_r: torch.Tensor, S: int, c: int, views: int, L_r=None, O_c=None, L_c=None) -> torch.Tensor:
     """The attention kernels' packed output (B * views, h, Mp, 32) -> (B, S*S, views * h * c): unpack_out_views (views = 1:
     unpack_out) in one kernel; with a second segment (O_c, L_c and the first's L_r: the halves of one softmax over two key
@@ -933,6 +976,9 @@ def attention_core(query: torch.Tensor, kproj: Optional[torch.Tensor], vproj: Op
     LSE_c = (LSE_c.reshape(B, V, heads, geom.Mp) + Gb[:, None]).reshape(Bp, heads, geom.Mp)
     Vp = F.pad(kvp[..., Cc:].reshape(Bp, TAP_N, heads, c), (0, pad_c)).permute(0, 2, 1, 3)          # (B', h, 12, 32)
     bv = F.pad(bkv[Cc:].float().reshape(1, heads, 1, c), (0, pad_c))
+    if O_r is not None and c % 4 == 0 and os.environ.get("BEVR_MERGE_TAP", "1") != "0":
+        # the two halves of the softmax merged and unpacked in one pass, the tap half's O = Rn Vpix + bv formed on the way
+        return merge_tap(O_r, LSE_r, Rn, LSE_c, Vp, bv.reshape(heads, HEAD_DIM), S, c, views if concat_views else 1)
     O_c = torch.matmul(Rn, Vp) + bv
     if O_r is None:
         return _unpacked(O_c, S, c, views, concat_views)

@@ -450,6 +450,16 @@ int bevr_merge_views_fwd(const float* O_r, const float* L_r, const float* O_c, c
 int bevr_merge_views_bwd(const float* dout, const float* O_r, const float* L_r, const float* O_c, const float* L_c,
                          float* dO_r, float* dL_r, float* dO_c, float* dL_c, int n_prob, int views, int heads, int S,
                          int Sp, int c, void* stream);
+/* The same with the tap segment's half formed on the way instead of passed in:  O_c = Rn Vp + bv  (csrc/attn_tap.h:
+ * V_n = sum_t w_t(n) Vpix_t + bv, so the tap kernels' output is the per-pixel weight sum Rn, not O).
+ *   Rn, dRn  [n_prob][heads][S * Sp][12] float (bevr_attn_tap_fwd's R, normalised by the caller)
+ *   Vp, dVp  [n_prob][heads][12][32] float: the 12 pixels' value rows per head (channels c .. 31 zero);  bv, dbv [heads][32]
+ *   dVp, dbv are ACCUMULATED (the caller zeroes them); everything else is written.  Other arguments as above. */
+int bevr_merge_tap_fwd(const float* O_r, const float* L_r, const float* Rn, const float* L_c, const float* Vp, const float* bv,
+                       float* out, int n_prob, int views, int heads, int S, int Sp, int c, void* stream);
+int bevr_merge_tap_bwd(const float* dout, const float* O_r, const float* L_r, const float* Rn, const float* L_c, const float* Vp,
+                       const float* bv, float* dO_r, float* dL_r, float* dRn, float* dL_c, float* dVp, float* dbv, int n_prob,
+                       int views, int heads, int S, int Sp, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The cotangent's way into the 16-bit backward kernels (ABI 6), one pass over dO and O:

@@ -156,3 +156,35 @@ def test_dwconv_res_gelu_matches_the_stock_chain(shape):
         e = rel_err(a, c)
         print(f"[dwconv_res_gelu {shape}] {name} {e:.1e}")
         assert e < 2e-5, (name, e)
+
+
+@pytest.mark.parametrize("B,V,h,S,c", [(2, 3, 2, 21, 32), (1, 2, 4, 40, 16), (1, 6, 2, 64, 32)])
+def test_merge_tap_matches_the_stock_chain(B, V, h, S, c):
+    """ops.merge_tap (bevr_merge_tap_fwd / _bwd): merge_views with O_c = Rn Vp + bv formed on the way, against
+    matmul + add + the stock merge chain; forward and the gradients of all six inputs"""
+    gen = torch.Generator().manual_seed(S + c)
+    Sp = 32 * ((S + 31) // 32)
+    Mp = S * Sp
+
+    def mk(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=gen) * scale).to(DEV).requires_grad_(True)
+    O_r, Rn = mk(B * V, h, Mp, 32), mk(B * V, h, Mp, 12)
+    L_r, L_c = mk(B * V, h, Mp, scale=5.0), mk(B * V, h, Mp, scale=5.0)
+    Vp0 = torch.randn(B * V, h, 12, 32, generator=gen)
+    bv0 = torch.randn(h, 32, generator=gen)
+    Vp0[..., c:] = 0.0                       # padded head channels are zero (ops.attention_core pads them)
+    bv0[..., c:] = 0.0
+    Vp, bv = Vp0.to(DEV).requires_grad_(True), bv0.to(DEV).requires_grad_(True)
+    ins = (O_r, L_r, Rn, L_c, Vp, bv)
+    got = ops.merge_tap(O_r, L_r, Rn, L_c, Vp, bv, S, c, V)
+    want = _chain(O_r, L_r, torch.matmul(Rn, Vp) + bv[None, :, None, :], L_c, S, c, V)
+    assert got.shape == want.shape and rel_err(got, want) < 3e-6
+    cot = torch.randn(want.shape, generator=gen).to(DEV)
+    g_got = torch.autograd.grad(got, ins, cot)
+    g_want = torch.autograd.grad(want, ins, cot)
+    for name, a, w_ in zip(("dO_r", "dL_r", "dRn", "dL_c", "dVp", "dbv"), g_got, g_want):
+        if name in ("dVp", "dbv"):           # the stock chain's gradient reaches the padded channels through nothing: zero there too
+            a, w_ = a[..., :c], w_[..., :c]
+        e = rel_err(a, w_)
+        print(f"[merge_tap {B=} {V=} {h=} {S=} {c=}] {name} {e:.1e}")
+        assert e < 3e-5, (name, e)

@@ -17,7 +17,8 @@ NAMES = {"attn_fwd_kernel": "bevr_attn_fwd", "attn_bwd_q_kernel": "bevr_attn_bwd
          "attn_tap_bwd_q_kernel": "bevr_attn_tap_bwd_q", "attn_tap_bwd_k_kernel": "bevr_attn_tap_bwd_k",
          "attn_gather_fwd_kernel": "bevr_attn_gather_fwd", "attn_slab_bwd_q_kernel": "bevr_attn_slab_bwd_q",
          "gram_mfma_kernel": "bevr_corr_fwd", "corr_bwd_slice_kernel": "bevr_corr_bwd",
-         "merge_views_fwd_kernel": "bevr_merge_views_fwd", "merge_views_bwd_kernel": "bevr_merge_views_bwd"}
+         "merge_views_fwd_kernel": "bevr_merge_views_fwd", "merge_views_bwd_kernel": "bevr_merge_views_bwd",
+         "merge_tap_fwd_kernel": "bevr_merge_views_fwd", "merge_tap_bwd_kernel": "bevr_merge_views_bwd"}
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(int))
 for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -25,7 +26,7 @@ for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            m = re.search(r"(attn_\w+_kernel|sample_\w+_kernel|kv_project_kernel|gram_mfma_kernel|corr_bwd_slice_kernel|merge_views_\w+_kernel)", r["Kernel_Name"])
+            m = re.search(r"(attn_\w+_kernel|sample_\w+_kernel|kv_project_kernel|gram_mfma_kernel|corr_bwd_slice_kernel|merge_views_\w+_kernel|merge_tap_\w+_kernel)", r["Kernel_Name"])
             if not m or m.group(1) not in NAMES:
                 continue
             k = NAMES[m.group(1)]
